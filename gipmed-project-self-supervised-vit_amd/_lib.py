@@ -1,0 +1,114 @@
+"""ctypes binding of include/gipvit.h (libgipvit_hip.so).
+
+The product path has NO fallback: if the shared library is missing or a symbol
+is absent, importing this module raises.  Field order / types mirror the header
+one to one; ``tests/test_abi.py`` checks every declared symbol is exported.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgipvit_hip.so")
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+def _struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+gv_patchify_args = _struct("gv_patchify_args", [
+    ("tiles", vp), ("patches", vp), ("n_img", i32), ("tile_h", i32), ("tile_w", i32), ("img_stride", i64),
+    ("n_win", i32), ("win_y", i32 * 16), ("win_x", i32 * 16), ("crop", i32), ("mean", f32 * 3), ("std", f32 * 3),
+    ("n_tiles", i32)])
+gv_layernorm_fwd_args = _struct("gv_layernorm_fwd_args", [
+    ("x", vp), ("x_stride", i64), ("gamma", vp), ("beta", vp), ("y", vp), ("mean", vp), ("rstd", vp),
+    ("rows", i32), ("D", i32), ("eps", f32)])
+gv_layernorm_bwd_args = _struct("gv_layernorm_bwd_args", [
+    ("dy", vp), ("x", vp), ("x_stride", i64), ("mean", vp), ("rstd", vp), ("gamma", vp),
+    ("g", vp), ("g_stride", i64), ("gb", vp), ("gb_stride", i64), ("partials", vp),
+    ("rows", i32), ("D", i32), ("g_init", i32)])
+gv_colsum_finalize_args = _struct("gv_colsum_finalize_args", [
+    ("partials", vp), ("n_blocks", i32), ("n_which", i32), ("which", i32), ("C", i32), ("out", vp), ("accumulate", i32)])
+gv_colsum_args = _struct("gv_colsum_args", [
+    ("x", vp), ("x_is_f32", i32), ("ld", i64), ("rows", i32), ("C", i32), ("workspace", vp), ("out", vp), ("accumulate", i32)])
+gv_linear_args = _struct("gv_linear_args", [
+    ("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldb", i64), ("ldc", i64),
+    ("trans_a", i32), ("trans_b", i32), ("c_is_f32", i32), ("epilogue", i32), ("bias", vp),
+    ("resid", vp), ("ldr", i64), ("aux_in", vp), ("ld_aux", i64), ("aux_out", vp), ("pos", vp), ("P", i32), ("alpha", f32)])
+gv_attention_fwd_args = _struct("gv_attention_fwd_args", [
+    ("qkv", vp), ("o", vp), ("lse", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32)])
+gv_attention_bwd_args = _struct("gv_attention_bwd_args", [
+    ("qkv", vp), ("o", vp), ("d_o", vp), ("lse", vp), ("dqkv", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32)])
+gv_cls_rows_args = _struct("gv_cls_rows_args", [("x", vp), ("cls", vp), ("pos", vp), ("n_img", i32), ("N", i32), ("D", i32)])
+gv_tokens_bwd_args = _struct("gv_tokens_bwd_args", [
+    ("g", vp), ("gpatch", vp), ("dpos", vp), ("dcls", vp), ("n_img", i32), ("N", i32), ("D", i32), ("accumulate", i32)])
+gv_small_matmul_args = _struct("gv_small_matmul_args", [
+    ("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("trans_a", i32), ("accumulate", i32)])
+gv_l2norm_fwd_args = _struct("gv_l2norm_fwd_args", [("x", vp), ("y", vp), ("inv_norm", vp), ("rows", i32), ("C", i32)])
+gv_l2norm_bwd_args = _struct("gv_l2norm_bwd_args", [("dy", vp), ("y", vp), ("inv_norm", vp), ("dx", vp), ("rows", i32), ("C", i32)])
+gv_weightnorm_fwd_args = _struct("gv_weightnorm_fwd_args", [("v", vp), ("g", vp), ("w", vp), ("rows", i32), ("C", i32)])
+gv_weightnorm_bwd_args = _struct("gv_weightnorm_bwd_args", [
+    ("dw", vp), ("v", vp), ("g", vp), ("dv", vp), ("dg", vp), ("rows", i32), ("C", i32), ("accumulate", i32)])
+gv_dino_loss_args = _struct("gv_dino_loss_args", [
+    ("student", vp), ("teacher", vp), ("center", vp), ("dstudent", vp), ("loss", vp), ("center_sum", vp), ("workspace", vp),
+    ("B", i32), ("V", i32), ("G", i32), ("K", i32), ("student_temp", f32), ("teacher_temp", f32), ("grad_scale", f32)])
+gv_center_update_args = _struct("gv_center_update_args", [
+    ("center", vp), ("center_sum", vp), ("K", i32), ("momentum", f32), ("inv_rows", f32)])
+gv_softmax_lsce_args = _struct("gv_softmax_lsce_args", [
+    ("logits", vp), ("target", vp), ("loss", vp), ("dlogits", vp), ("prob", vp), ("B", i32), ("C", i32), ("smoothing", f32)])
+gv_gather_cls_args = _struct("gv_gather_cls_args", [("x", vp), ("y", vp), ("n_img", i32), ("N", i32), ("D", i32)])
+gv_cast_bf16_args = _struct("gv_cast_bf16_args", [("src", vp), ("dst", vp), ("n", i64)])
+gv_sumsq_args = _struct("gv_sumsq_args", [("x", vp), ("n", i64), ("workspace", vp), ("out", vp), ("accumulate", i32)])
+gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
+    ("p", vp), ("grad", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("teacher", vp), ("teacher_bf16", vp), ("n", i64),
+    ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bias_corr1", f32), ("bias_corr2", f32),
+    ("grad_scale", f32), ("clip_norm", f32), ("gnorm_sq", vp), ("teacher_momentum", f32)])
+
+# entry point -> argument struct (every `int gv_*(const args*, void* stream)` of the header)
+ENTRY_POINTS = {
+    "gv_patchify": gv_patchify_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
+    "gv_colsum_finalize": gv_colsum_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
+    "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_cls_rows": gv_cls_rows_args,
+    "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,
+    "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,
+    "gv_dino_loss": gv_dino_loss_args, "gv_center_update": gv_center_update_args, "gv_softmax_lsce": gv_softmax_lsce_args,
+    "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_sumsq": gv_sumsq_args,
+    "gv_adamw_ema": gv_adamw_ema_args,
+}
+PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target")
+
+EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_POS, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
+LN_PARTIAL_BLOCKS = 512
+
+
+class GipvitError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, st in ENTRY_POINTS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [C.POINTER(st), vp]
+        fn.restype = C.c_int
+    lib.gv_version.restype = C.c_int
+    lib.gv_last_error.restype = C.c_char_p
+    lib.gv_target.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+def call(name: str, args, stream: int) -> None:
+    """Invoke an entry point; raise GipvitError with gv_last_error() on failure."""
+    rc = getattr(lib, name)(C.byref(args), vp(stream))
+    if rc != 0:
+        raise GipvitError(f"{name} failed (rc={rc}): {lib.gv_last_error().decode()}")

@@ -1,0 +1,59 @@
+"""Build libgipvit_hip.so (gfx950) in-tree with hipcc.  No torch involved."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libgipvit_hip.so")
+SOURCES = ["abi", "gemm", "layernorm", "rowops", "patch", "attention", "dino_loss", "optim"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "gv_common.h"), os.path.join(HERE, "..", "include", "gipvit.h")]
+
+    def compile_one(name):
+        src, obj = os.path.join(CSRC, name + ".hip"), os.path.join(OBJ, name + ".o")
+        if force or _stale(obj, [src] + headers):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {name}.hip:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,434 @@
+// Fused multi-head attention forward / backward for short sequences (N <= 288,
+// head_dim 64) -- replaces Attention.forward's q@k^T, softmax, attn@v ATen calls
+// (vit.pyc@L119-131) and their autograd backward; the N x N score matrix never
+// reaches HBM.  A whole sequence fits one workgroup's LDS.
+//
+// Common LDS image: [rows = tokens][64 d] bf16, 128-B rows, 16-B chunk index XOR
+// (row & 7).  Filled by LDS-DMA with the swizzle on the per-lane SOURCE address.  The
+// same image serves k-contiguous fragment reads (ds_read_b128) and hardware-transposed
+// reads (ds_read_b64_tr_b16: 4 rows x 16 columns per 16-lane group), both conflict-free.
+//
+// forward : a wave owns 32 queries.  S^T = K Q^T (keys on MFMA rows, queries on lanes) so
+//           the row softmax is an in-lane reduction + 2 wavefront shuffles, and P^T is
+//           already the B operand of O^T = V^T P^T (accumulator-as-operand, no LDS trip).
+// backward: a wave owns 32 keys.  S, dP with keys on lanes; P, dS are then already the B
+//           operands of dV^T += dO^T P and dK^T += Q^T dS, so dK/dV need no cross-wave
+//           sum.  Only dS crosses LDS (transposed image) for dQ = dS K.
+#include "gv_common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned short attn_zero_page[128];
+
+__device__ __forceinline__ void glds16(const void* src, GV_LDS char* dst) {
+    __builtin_amdgcn_global_load_lds((const GV_GLOBAL void*)src, (GV_LDS void*)dst, 16, 0, 0);
+}
+
+// stage rows [0, nrows_pad) of a [token][64] slice; rows >= nvalid are zero filled
+__device__ __forceinline__ void stage_rows(const bf16* __restrict__ gbase, long ld, int nvalid, int nrows_pad,
+                                           GV_LDS char* img, int wave, int nwaves, int lane) {
+    const int pieces = nrows_pad >> 3;
+    for (int piece = wave; piece < pieces; piece += nwaves) {
+        const int r = piece * 8 + (lane >> 3);
+        const int slot = lane & 7;
+        const int c = slot ^ (r & 7);
+        const bf16* src = r < nvalid ? gbase + (long)r * ld + c * 8 : (const bf16*)attn_zero_page + slot * 8;
+        glds16(src, img + __builtin_amdgcn_readfirstlane(piece * 1024));
+    }
+}
+
+__device__ __forceinline__ bf16x8 read_nat(GV_LDS char* img, int row, int chunk) {
+    return *(GV_LDS bf16x8*)(img + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+// transposed read: this lane addresses `row`, 16-column block dt, quarter p (0..3)
+__device__ __forceinline__ bf16x4 read_tr(GV_LDS char* img, int row, int dt, int p) {
+    const int c16 = 2 * dt + (p >> 1);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (GV_LDS bf16x4*)(img + row * 128 + ((c16 ^ (row & 7)) << 4) + 8 * (p & 1)));
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+    return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(gv_attention_fwd_args a, int n_pairs) {
+    constexpr int NQB = NKT / 2;
+    constexpr int PAIRS = NQB >= 4 ? 1 : 4 / NQB;
+    constexpr int WPP = 4 / PAIRS;
+    constexpr int NP = NKT * 16;
+    constexpr int IMG = NP * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GV_LDS char* smem = (GV_LDS char*)smem_raw;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = a.N, H = a.H;
+    const long ld = 3L * H * 64;
+    const bf16* qkv = (const bf16*)a.qkv;
+
+    for (int pr = 0; pr < PAIRS; ++pr) {
+        int pair = blockIdx.x * PAIRS + pr;
+        pair = pair < n_pairs ? pair : n_pairs - 1;
+        const int img = pair / H, h = pair - img * H;
+        const bf16* base = qkv + (long)img * N * ld + h * 64;
+        stage_rows(base + H * 64, ld, N, NP, smem + (pr * 2 + 0) * IMG, wave, 4, lane);
+        stage_rows(base + 2 * H * 64, ld, N, NP, smem + (pr * 2 + 1) * IMG, wave, 4, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lp = wave / WPP, wq = wave % WPP;
+    const int pair_raw = blockIdx.x * PAIRS + lp;
+    const bool valid = pair_raw < n_pairs;
+    const int pair = valid ? pair_raw : n_pairs - 1;
+    const int img = pair / H, h = pair - img * H;
+    const bf16* qbase = qkv + (long)img * N * ld + h * 64;
+    GV_LDS char* Kimg = smem + (lp * 2 + 0) * IMG;
+    GV_LDS char* Vimg = smem + (lp * 2 + 1) * IMG;
+    const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
+    const float c = a.scale * 1.4426950408889634f;
+
+    for (int qb = wq; qb < NQB; qb += WPP) {
+        if (qb * 32 >= N) break;
+        bf16x8 qf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            int qrow = qb * 32 + qt * 16 + li;
+            qrow = qrow < N ? qrow : N - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *(const bf16x8*)(qbase + (long)qrow * ld + ks * 32 + g * 8);
+        }
+        f32x4 s[NKT][2];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = read_nat(Kimg, kt * 16 + li, ks * 4 + g);
+                s[kt][0] = MFMA16(kf, qf[0][ks], s[kt][0]);
+                s[kt][1] = MFMA16(kf, qf[1][ks], s[kt][1]);
+            }
+        }
+        // softmax over keys: key = kt*16 + 4g + r lives in (kt, r) of lanes {li, li+16, li+32, li+48}
+        float mx[2] = {-INFINITY, -INFINITY}, sum[2] = {0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = kt * 16 + 4 * g + r < N;
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const float v = ok ? s[kt][qt][r] : -INFINITY;
+                    s[kt][qt][r] = v;
+                    mx[qt] = fmaxf(mx[qt], v);
+                }
+            }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
+            mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f((s[kt][qt][r] - mx[qt]) * c);
+                    s[kt][qt][r] = p;
+                    sum[qt] += p;
+                }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            sum[qt] += __shfl_xor(sum[qt], 16, 64);
+            sum[qt] += __shfl_xor(sum[qt], 32, 64);
+        }
+        // O^T[d][q] = sum_key V[key][d] P^T[key][q]
+        f32x4 o[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { o[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int u = 0; u < NKT / 2; ++u) {
+            const bf16x8 pf0 = pack8(s[2 * u][0], s[2 * u + 1][0]);
+            const bf16x8 pf1 = pack8(s[2 * u][1], s[2 * u + 1][1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vf = cat8(read_tr(Vimg, (2 * u) * 16 + 4 * g + q4, dt, p4),
+                                       read_tr(Vimg, (2 * u + 1) * 16 + 4 * g + q4, dt, p4));
+                o[dt][0] = MFMA16(vf, pf0, o[dt][0]);
+                o[dt][1] = MFMA16(vf, pf1, o[dt][1]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int q = qb * 32 + qt * 16 + li;
+                if (q < N) {
+                    const float inv = 1.0f / sum[qt];
+                    bf16* dst = (bf16*)a.o + ((long)img * N + q) * (H * 64) + h * 64 + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        *(bf16x4*)(dst + dt * 16) = bf16x4{(bf16)(o[dt][qt][0] * inv), (bf16)(o[dt][qt][1] * inv),
+                                                           (bf16)(o[dt][qt][2] * inv), (bf16)(o[dt][qt][3] * inv)};
+                    if (g == 0) a.lse[((long)img * H + h) * N + q] = mx[qt] * a.scale + __logf(sum[qt]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64) void attn_bwd_kernel(gv_attention_bwd_args a, int n_pairs) {
+    constexpr int NKB = NKT / 2;                       // 32-key blocks = waves per pair
+    constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
+    constexpr int NW = NKB * PAIRS;                    // waves per workgroup
+    constexpr int NP = NKT * 16;
+    constexpr int IMG = NP * 128;
+    constexpr int DST = NP * 64;                       // dS^T image: [key][32 q] bf16
+    constexpr int PER_PAIR = 3 * IMG + DST + 2 * NP * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GV_LDS char* smem = (GV_LDS char*)smem_raw;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = a.N, H = a.H;
+    const long ld = 3L * H * 64, ldo = (long)H * 64;
+    const bf16* qkv = (const bf16*)a.qkv;
+
+    // ---- stage Q, K, dO of every pair; delta and lse into LDS
+    for (int pr = 0; pr < PAIRS; ++pr) {
+        int pair = blockIdx.x * PAIRS + pr;
+        pair = pair < n_pairs ? pair : n_pairs - 1;
+        const int img = pair / H, h = pair - img * H;
+        const bf16* base = qkv + (long)img * N * ld + h * 64;
+        GV_LDS char* P0 = smem + pr * PER_PAIR;
+        stage_rows(base, ld, N, NP, P0, wave, NW, lane);
+        stage_rows(base + H * 64, ld, N, NP, P0 + IMG, wave, NW, lane);
+        stage_rows((const bf16*)a.d_o + (long)img * N * ldo + h * 64, ldo, N, NP, P0 + 2 * IMG, wave, NW, lane);
+    }
+    for (int u = threadIdx.x; u < PAIRS * NP; u += NW * 64) {
+        const int pr = u / NP, q = u - pr * NP;
+        int pair = blockIdx.x * PAIRS + pr;
+        pair = pair < n_pairs ? pair : n_pairs - 1;
+        const int img = pair / H, h = pair - img * H;
+        GV_LDS float* dl = (GV_LDS float*)(smem + pr * PER_PAIR + 3 * IMG + DST);
+        float d = 0.f, l = 0.f;
+        if (q < N) {
+            const bf16* orow = (const bf16*)a.o + ((long)img * N + q) * ldo + h * 64;
+            const bf16* drow = (const bf16*)a.d_o + ((long)img * N + q) * ldo + h * 64;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bf16x8 x = *(const bf16x8*)(orow + i * 8), y = *(const bf16x8*)(drow + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += (float)x[j] * (float)y[j];
+            }
+            l = a.lse[((long)img * H + h) * N + q];
+        }
+        dl[q] = d;
+        dl[NP + q] = l;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lp = wave / NKB, kb = wave % NKB;        // local pair, this wave's 32-key block
+    const int pair_raw = blockIdx.x * PAIRS + lp;
+    const bool valid = pair_raw < n_pairs;
+    const int pair = valid ? pair_raw : n_pairs - 1;
+    const int img = pair / H, h = pair - img * H;
+    GV_LDS char* Qimg = smem + lp * PER_PAIR;
+    GV_LDS char* Kimg = Qimg + IMG;
+    GV_LDS char* Dimg = Qimg + 2 * IMG;
+    GV_LDS char* dsT = Qimg + 3 * IMG;
+    GV_LDS float* delta = (GV_LDS float*)(dsT + DST);
+    GV_LDS float* lse = delta + NP;
+    const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
+    const float c = a.scale * 1.4426950408889634f;
+
+    // this wave's K and V fragments (B operands: lane = key, 8 consecutive d)
+    bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = kb * 32 + kt * 16 + li;
+        const int keyc = key < N ? key : N - 1;
+        const bf16* vrow = qkv + ((long)img * N + keyc) * ld + 2 * H * 64 + h * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[kt][ks] = read_nat(Kimg, key, ks * 4 + g);
+            vf[kt][ks] = *(const bf16x8*)(vrow + ks * 32 + g * 8);
+        }
+    }
+    f32x4 dv[4][2], dk[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nqc = (N + 31) >> 5;
+    for (int qc = 0; qc < nqc; ++qc) {
+        // ---- phase A: S, dP for [32 q] x [this wave's 32 keys]
+        f32x4 s[2][2], dp[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qrow = qc * 32 + qt * 16 + li;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 qa = read_nat(Qimg, qrow, ks * 4 + g);
+                const bf16x8 da = read_nat(Dimg, qrow, ks * 4 + g);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    s[qt][kt] = MFMA16(qa, kf[kt][ks], s[qt][kt]);
+                    dp[qt][kt] = MFMA16(da, vf[kt][ks], dp[qt][kt]);
+                }
+            }
+        }
+        // P = exp(scale*S - lse[q]); dS = P * (dP - delta[q]) * scale.  rows q = 4g + r, col key = li
+        f32x4 pv[2][2], ds[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q0 = qc * 32 + qt * 16 + 4 * g;
+            const f32x4 l4 = *(GV_LDS f32x4*)(lse + q0);
+            const f32x4 d4 = *(GV_LDS f32x4*)(delta + q0);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bool kok = kb * 32 + kt * 16 + li < N;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = kok && (q0 + r < N);
+                    const float p = ok ? exp2f(s[qt][kt][r] * c - l4[r] * 1.4426950408889634f) : 0.f;
+                    pv[qt][kt][r] = p;
+                    ds[qt][kt][r] = p * (dp[qt][kt][r] - d4[r]) * a.scale;
+                }
+            }
+        }
+        // dV^T += dO^T P ; dK^T += Q^T dS   (reduction over the chunk's 32 queries)
+        {
+            bf16x8 pb[2], sb[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { pb[kt] = pack8(pv[0][kt], pv[1][kt]); sb[kt] = pack8(ds[0][kt], ds[1][kt]); }
+            const int r0 = qc * 32 + 4 * g + q4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 dot = cat8(read_tr(Dimg, r0, dt, p4), read_tr(Dimg, r0 + 16, dt, p4));
+                const bf16x8 qtt = cat8(read_tr(Qimg, r0, dt, p4), read_tr(Qimg, r0 + 16, dt, p4));
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    dv[dt][kt] = MFMA16(dot, pb[kt], dv[dt][kt]);
+                    dk[dt][kt] = MFMA16(qtt, sb[kt], dk[dt][kt]);
+                }
+            }
+        }
+        // dS^T image [key][32 q]: 64-B rows, 32-B half index XOR ((key >> 2) & 1)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = kb * 32 + kt * 16 + li;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+                *(GV_LDS bf16x4*)(dsT + key * 64 + ((qt ^ ((key >> 2) & 1)) << 5) + g * 8) =
+                    bf16x4{(bf16)ds[qt][kt][0], (bf16)ds[qt][kt][1], (bf16)ds[qt][kt][2], (bf16)ds[qt][kt][3]};
+        }
+        __syncthreads();
+        // ---- phase B: dQ^T[d][q] = sum_key K[key][d] dS[q][key]; 8 (qt, dt) tiles over the pair's waves
+        for (int tile = kb; tile < 8; tile += NKB) {
+            const int qt = tile >> 2, dt = tile & 3;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKB; ++ks) {
+                // k-slot (g, j): key = 32 ks + 16 (j >> 2) + 4 g + (j & 3)
+                const int k0 = ks * 32 + 4 * g + q4;
+                const bf16x8 ka = cat8(read_tr(Kimg, k0, dt, p4), read_tr(Kimg, k0 + 16, dt, p4));
+                const int h0 = qt ^ ((k0 >> 2) & 1), h1 = qt ^ (((k0 + 16) >> 2) & 1);
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(dsT + k0 * 64 + (h0 << 5) + p4 * 8));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(dsT + (k0 + 16) * 64 + (h1 << 5) + p4 * 8));
+                acc = MFMA16(ka, cat8(lo, hi), acc);
+            }
+            const int q = qc * 32 + qt * 16 + li;
+            if (valid && q < N)
+                *(bf16x4*)((bf16*)a.dqkv + ((long)img * N + q) * ld + h * 64 + dt * 16 + 4 * g) =
+                    bf16x4{(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
+        }
+        __syncthreads();
+    }
+    // ---- dK, dV: lane = key, rows d = 16 dt + 4 g + r
+    if (valid) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = kb * 32 + kt * 16 + li;
+            if (key < N) {
+                bf16* dst = (bf16*)a.dqkv + ((long)img * N + key) * ld + h * 64 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *(bf16x4*)(dst + H * 64 + dt * 16) = bf16x4{(bf16)dk[dt][kt][0], (bf16)dk[dt][kt][1], (bf16)dk[dt][kt][2], (bf16)dk[dt][kt][3]};
+                    *(bf16x4*)(dst + 2 * H * 64 + dt * 16) = bf16x4{(bf16)dv[dt][kt][0], (bf16)dv[dt][kt][1], (bf16)dv[dt][kt][2], (bf16)dv[dt][kt][3]};
+                }
+            }
+        }
+    }
+}
+
+template <int NKT> int launch_fwd(const gv_attention_fwd_args* a, hipStream_t s) {
+    constexpr int NQB = NKT / 2, PAIRS = NQB >= 4 ? 1 : 4 / NQB;
+    constexpr int LDS = PAIRS * 2 * NKT * 16 * 128;
+    auto kern = attn_fwd_kernel<NKT>;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { gv_set_error("gv_attention_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        done = true;
+    }
+    const int n_pairs = a->n_img * a->H;
+    hipLaunchKernelGGL(kern, dim3((n_pairs + PAIRS - 1) / PAIRS), dim3(256), LDS, s, *a, n_pairs);
+    GV_LAUNCH_CHECK("gv_attention_fwd");
+    return GV_OK;
+}
+
+template <int NKT> int launch_bwd(const gv_attention_bwd_args* a, hipStream_t s) {
+    constexpr int NKB = NKT / 2, PAIRS = NKB >= 4 ? 1 : 4 / NKB, NW = NKB * PAIRS, NP = NKT * 16;
+    constexpr int LDS = PAIRS * (3 * NP * 128 + NP * 64 + 2 * NP * 4);
+    auto kern = attn_bwd_kernel<NKT>;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { gv_set_error("gv_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        done = true;
+    }
+    const int n_pairs = a->n_img * a->H;
+    hipLaunchKernelGGL(kern, dim3((n_pairs + PAIRS - 1) / PAIRS), dim3(NW * 64), LDS, s, *a, n_pairs);
+    GV_LAUNCH_CHECK("gv_attention_bwd");
+    return GV_OK;
+}
+
+}  // namespace
+
+extern "C" int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->qkv && a->o && a->lse, GV_E_NULL, "gv_attention_fwd: null pointer");
+    GV_REQUIRE(a->n_img > 0 && a->H > 0 && a->N > 0 && a->N <= 288, GV_E_SHAPE, "gv_attention_fwd: need 0 < N <= 288 (got %d)", a->N);
+    GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16), GV_E_ALIGN, "gv_attention_fwd: qkv/o must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (a->N <= 32) return launch_fwd<2>(a, s);
+    if (a->N <= 64) return launch_fwd<4>(a, s);
+    if (a->N <= 128) return launch_fwd<8>(a, s);
+    if (a->N <= 224) return launch_fwd<14>(a, s);
+    return launch_fwd<18>(a, s);
+}
+
+extern "C" int gv_attention_bwd(const gv_attention_bwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->qkv && a->o && a->d_o && a->lse && a->dqkv, GV_E_NULL, "gv_attention_bwd: null pointer");
+    GV_REQUIRE(a->n_img > 0 && a->H > 0 && a->N > 0 && a->N <= 288, GV_E_SHAPE, "gv_attention_bwd: need 0 < N <= 288 (got %d)", a->N);
+    GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16) && gv_aligned(a->d_o, 16) && gv_aligned(a->dqkv, 16), GV_E_ALIGN,
+               "gv_attention_bwd: buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (a->N <= 32) return launch_bwd<2>(a, s);
+    if (a->N <= 64) return launch_bwd<4>(a, s);
+    if (a->N <= 128) return launch_bwd<8>(a, s);
+    if (a->N <= 224) return launch_bwd<14>(a, s);
+    return launch_bwd<18>(a, s);
+}

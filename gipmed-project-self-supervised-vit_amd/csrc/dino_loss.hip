@@ -1,0 +1,120 @@
+// Fused DINO head loss: student log-softmax(s / tau_s), teacher softmax((t - c) /
+// tau_t), cross-entropy over the (teacher global crop iq, student crop v != iq) pairs,
+// its gradient w.r.t. the student logits and the teacher center partial sum.
+// The reference has no DINO loop; spec = DINO paper Alg. 1 (rows D2/D3).
+//
+// HBM-bound: pass 1 (row_stats) reads every logit once, pass 2 reads them once more and
+// writes the bf16 gradient: (V+G)*B*K*4*2 + V*B*K*2 bytes per call.
+//   loss = 1/(n_pairs B) sum_{b, iq, v != iq} -sum_k t_iq[b,k] logp_v[b,k]
+//   d loss / d s_v[b,k] = (n_v p_v[b,k] - sum_{iq != v} t_iq[b,k]) / (n_pairs B tau_s)
+#include "gv_common.h"
+
+namespace {
+
+constexpr int MAXV = 16, MAXG = 4;
+
+// one block per logits row: running max / sum-exp of the temperature-scaled row
+__global__ __launch_bounds__(256) void row_stats_kernel(gv_dino_loss_args a) {
+    __shared__ float red_m[4], red_s[4];
+    const int row = blockIdx.x;
+    const int ns = a.V * a.B;
+    const bool teacher = row >= ns;
+    const float* x = teacher ? a.teacher + (long)(row - ns) * a.K : a.student + (long)row * a.K;
+    const float inv_t = 1.0f / (teacher ? a.teacher_temp : a.student_temp);
+    float m = -INFINITY, s = 0.f;
+    for (int k = threadIdx.x * 4; k < a.K; k += 1024) {
+        f32x4 v = *(const f32x4*)(x + k);
+        if (teacher) { f32x4 c = *(const f32x4*)(a.center + k); v -= c; }
+        v *= inv_t;
+        const float lm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (lm > m) { s *= __expf(m - lm); m = lm; }
+        s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+    }
+    const float wm = wave_max(m);
+    s = (m == -INFINITY) ? 0.f : s * __expf(m - wm);   // idle lanes when K < 1024
+    s = wave_sum(s);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red_m[wave] = wm; red_s[wave] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+        float S = 0.f;
+        for (int w = 0; w < 4; ++w) S += red_s[w] * __expf(red_m[w] - M);
+        a.workspace[2 * row] = M;
+        a.workspace[2 * row + 1] = __logf(S);
+    }
+}
+
+// grid (K/256, bsplit); thread = one class k, loops over its slice of the batch
+__global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int b_per, float coef, float inv_pairs_b) {
+    __shared__ float red[4];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int b0 = blockIdx.y * b_per, b1 = min(a.B, b0 + b_per);
+    const int V = a.V, G = a.G, B = a.B, K = a.K;
+    const int ns = V * B;
+    const float inv_ts = 1.0f / a.student_temp, inv_tt = 1.0f / a.teacher_temp;
+    float loss = 0.f, csum = 0.f;
+    if (k < K) {
+        const float c = a.center[k];
+        for (int b = b0; b < b1; ++b) {
+            float t[MAXG], tsum = 0.f;
+#pragma unroll
+            for (int iq = 0; iq < MAXG; ++iq) {
+                if (iq < G) {
+                    const int row = ns + iq * B + b;
+                    const float raw = a.teacher[(long)(iq * B + b) * K + k];
+                    csum += raw;
+                    t[iq] = __expf((raw - c) * inv_tt - a.workspace[2 * row] - a.workspace[2 * row + 1]);
+                    tsum += t[iq];
+                } else t[iq] = 0.f;
+            }
+#pragma unroll 2
+            for (int v = 0; v < V; ++v) {
+                const int row = v * B + b;
+                const float s = a.student[(long)row * K + k] * inv_ts;
+                const float logp = s - a.workspace[2 * row] - a.workspace[2 * row + 1];
+                const float p = __expf(logp);
+                float ts = tsum, nv = (float)G;
+                if (v < G) { ts -= (v == 0 ? t[0] : v == 1 ? t[1] : v == 2 ? t[2] : t[3]); nv -= 1.f; }
+                loss -= ts * logp;
+                ((bf16*)a.dstudent)[(long)row * K + k] = (bf16)(coef * (nv * p - ts));
+            }
+        }
+        atomicAdd(a.center_sum + k, csum);
+    }
+    loss = wave_sum(loss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.loss, (red[0] + red[1] + red[2] + red[3]) * inv_pairs_b);
+}
+
+}  // namespace
+
+extern "C" int gv_dino_loss(const gv_dino_loss_args* a, void* stream) {
+    GV_REQUIRE(a && a->student && a->teacher && a->center && a->dstudent && a->loss && a->center_sum && a->workspace,
+               GV_E_NULL, "gv_dino_loss: null pointer");
+    GV_REQUIRE(a->B > 0 && a->V >= 2 && a->V <= MAXV && a->G >= 1 && a->G <= MAXG && a->G <= a->V, GV_E_SHAPE,
+               "gv_dino_loss: need 1 <= G <= %d, G <= V <= %d (got V=%d G=%d)", MAXG, MAXV, a->V, a->G);
+    GV_REQUIRE(a->K > 0 && a->K % 4 == 0, GV_E_SHAPE, "gv_dino_loss: K must be a positive multiple of 4");
+    GV_REQUIRE(a->student_temp > 0.f && a->teacher_temp > 0.f, GV_E_SHAPE, "gv_dino_loss: temperatures must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(a->loss, 0, sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(a->center_sum, 0, sizeof(float) * a->K, s);
+    if (e != hipSuccess) GV_FAIL((int)e, "gv_dino_loss: memset failed: %s", hipGetErrorString(e));
+    const int rows = (a->V + a->G) * a->B;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(rows), dim3(256), 0, s, *a);
+    GV_LAUNCH_CHECK("gv_dino_loss(row_stats)");
+    const int kblocks = (a->K + 255) / 256;
+    int bsplit = (1024 + kblocks - 1) / kblocks;
+    if (bsplit > a->B) bsplit = a->B;
+    if (bsplit < 1) bsplit = 1;
+    const int b_per = (a->B + bsplit - 1) / bsplit;
+    bsplit = (a->B + b_per - 1) / b_per;
+    const int n_pairs = a->G * (a->V - 1);
+    const float inv_pairs_b = 1.0f / ((float)n_pairs * (float)a->B);
+    const float gs = a->grad_scale == 0.f ? 1.f : a->grad_scale;
+    const float coef = gs * inv_pairs_b / a->student_temp;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(kblocks, bsplit), dim3(256), 0, s, *a, b_per, coef, inv_pairs_b);
+    GV_LAUNCH_CHECK("gv_dino_loss(loss_grad)");
+    return GV_OK;
+}

@@ -1,0 +1,303 @@
+// Small HBM-bound row / elementwise kernels of the hot path: token assembly
+// (prepare_tokens, vit.pyc@L235-246), DINOHead tail (F.normalize + weight_norm,
+// vit.pyc@L315-330), CLS gather, casts, reductions, the supervised softmax+LSCE loss
+// (reference train.py:1046,1053) and the positional-embedding resampling matmul.
+#include "gv_common.h"
+
+namespace {
+
+__global__ void cls_rows_kernel(gv_cls_rows_args a) {
+    const int i = blockIdx.x;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x)
+        a.x[(long)i * a.N * a.D + d] = a.cls[d] + a.pos[d];
+}
+
+// grid (N tokens, D/256): each thread sums one (token, column) over the images;
+// patch rows are also re-emitted compact in bf16.
+__global__ void tokens_bwd_kernel(gv_tokens_bwd_args a) {
+    const int t = blockIdx.x;
+    const int d = blockIdx.y * blockDim.x + threadIdx.x;
+    if (d >= a.D) return;
+    const int P = a.N - 1;
+    float s = 0.f;
+    for (int i = 0; i < a.n_img; ++i) {
+        const float v = a.g[((long)i * a.N + t) * a.D + d];
+        s += v;
+        if (t > 0) ((bf16*)a.gpatch)[((long)i * P + (t - 1)) * a.D + d] = (bf16)v;
+    }
+    float* o = a.dpos + (long)t * a.D + d;
+    *o = a.accumulate ? *o + s : s;
+    if (t == 0 && a.dcls) a.dcls[d] = a.accumulate ? a.dcls[d] + s : s;
+}
+
+__global__ void small_matmul_kernel(gv_small_matmul_args a) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (n >= a.N) return;
+    float s = 0.f;
+    for (int k = 0; k < a.K; ++k) {
+        const float av = a.trans_a ? a.A[(long)k * a.M + m] : a.A[(long)m * a.K + k];
+        s += av * a.B[(long)k * a.N + n];
+    }
+    float* c = a.C + (long)m * a.N + n;
+    *c = a.accumulate ? *c + s : s;
+}
+
+// one wave per row, C = 256 (DINOHead bottleneck): 4 columns per lane
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(gv_l2norm_fwd_args a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* x = a.x + (long)row * a.C;
+    float s = 0.f;
+    for (int c = lane * 4; c < a.C; c += 256) { f32x4 v = *(const f32x4*)(x + c); s += v[0]*v[0] + v[1]*v[1] + v[2]*v[2] + v[3]*v[3]; }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    bf16* y = (bf16*)a.y + (long)row * a.C;
+    for (int c = lane * 4; c < a.C; c += 256) {
+        f32x4 v = *(const f32x4*)(x + c);
+        *(bf16x4*)(y + c) = bf16x4{(bf16)(v[0]*inv), (bf16)(v[1]*inv), (bf16)(v[2]*inv), (bf16)(v[3]*inv)};
+    }
+    if (lane == 0) a.inv_norm[row] = inv;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(gv_l2norm_bwd_args a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* dy = a.dy + (long)row * a.C;
+    const bf16* y = (const bf16*)a.y + (long)row * a.C;
+    float s = 0.f;
+    for (int c = lane * 4; c < a.C; c += 256) {
+        f32x4 d = *(const f32x4*)(dy + c); bf16x4 yy = *(const bf16x4*)(y + c);
+        s += d[0]*(float)yy[0] + d[1]*(float)yy[1] + d[2]*(float)yy[2] + d[3]*(float)yy[3];
+    }
+    s = wave_sum(s);
+    const float inv = a.inv_norm[row];
+    bf16* dx = (bf16*)a.dx + (long)row * a.C;
+    for (int c = lane * 4; c < a.C; c += 256) {
+        f32x4 d = *(const f32x4*)(dy + c); bf16x4 yy = *(const bf16x4*)(y + c);
+        *(bf16x4*)(dx + c) = bf16x4{(bf16)((d[0] - (float)yy[0]*s)*inv), (bf16)((d[1] - (float)yy[1]*s)*inv),
+                                    (bf16)((d[2] - (float)yy[2]*s)*inv), (bf16)((d[3] - (float)yy[3]*s)*inv)};
+    }
+}
+
+__global__ __launch_bounds__(256) void weightnorm_fwd_kernel(gv_weightnorm_fwd_args a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* v = a.v + (long)row * a.C;
+    float s = 0.f;
+    for (int c = lane * 4; c < a.C; c += 256) { f32x4 x = *(const f32x4*)(v + c); s += x[0]*x[0] + x[1]*x[1] + x[2]*x[2] + x[3]*x[3]; }
+    const float sc = a.g[row] / sqrtf(wave_sum(s));
+    bf16* w = (bf16*)a.w + (long)row * a.C;
+    for (int c = lane * 4; c < a.C; c += 256) {
+        f32x4 x = *(const f32x4*)(v + c);
+        *(bf16x4*)(w + c) = bf16x4{(bf16)(x[0]*sc), (bf16)(x[1]*sc), (bf16)(x[2]*sc), (bf16)(x[3]*sc)};
+    }
+}
+
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(gv_weightnorm_bwd_args a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* v = a.v + (long)row * a.C;
+    const float* dw = a.dw + (long)row * a.C;
+    float nn = 0.f, dot = 0.f;
+    for (int c = lane * 4; c < a.C; c += 256) {
+        f32x4 x = *(const f32x4*)(v + c); f32x4 d = *(const f32x4*)(dw + c);
+        nn += x[0]*x[0] + x[1]*x[1] + x[2]*x[2] + x[3]*x[3];
+        dot += x[0]*d[0] + x[1]*d[1] + x[2]*d[2] + x[3]*d[3];
+    }
+    nn = wave_sum(nn); dot = wave_sum(dot);
+    const float inv = 1.0f / sqrtf(nn);
+    const float gs = a.g[row] * inv;          // g / ||v||
+    const float vd = dot * inv;               // vhat . dw
+    float* dv = a.dv + (long)row * a.C;
+    for (int c = lane * 4; c < a.C; c += 256) {
+        f32x4 x = *(const f32x4*)(v + c); f32x4 d = *(const f32x4*)(dw + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = gs * (d[j] - x[j] * inv * vd);
+        if (a.accumulate) { f32x4 p = *(const f32x4*)(dv + c); o += p; }
+        *(f32x4*)(dv + c) = o;
+    }
+    if (lane == 0 && a.dg) a.dg[row] = a.accumulate ? a.dg[row] + vd : vd;
+}
+
+__global__ void gather_cls_kernel(gv_gather_cls_args a) {
+    const int i = blockIdx.x;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x)
+        ((bf16*)a.y)[(long)i * a.D + d] = (bf16)a.x[(long)i * a.N * a.D + d];
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(gv_cast_bf16_args a) {
+    const long n4 = a.n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = ((const f32x4*)a.src)[i];
+        ((bf16x4*)a.dst)[i] = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        ((bf16*)a.dst)[i] = (bf16)a.src[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(gv_sumsq_args a) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long n4 = a.n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = ((const f32x4*)a.x)[i];
+        s += v[0]*v[0] + v[1]*v[1] + v[2]*v[2] + v[3]*v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) { const float v = a.x[(n4 << 2) + threadIdx.x]; s += v * v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.workspace[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* ws, int n, float* out, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += ws[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float t = red[0] + red[1] + red[2] + red[3]; out[0] = accumulate ? out[0] + t : t; }
+}
+
+__global__ void center_update_kernel(gv_center_update_args a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < a.K) a.center[k] = a.center[k] * a.momentum + a.center_sum[k] * a.inv_rows * (1.0f - a.momentum);
+}
+
+// one thread per sample, C <= 64.  loss = mean_b[(1-s) * nll + s * smooth] on
+// logp = log_softmax(softmax(logits)); analytic gradient through both softmaxes.
+__global__ void softmax_lsce_kernel(gv_softmax_lsce_args a) {
+    __shared__ float red[256];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f;
+    if (b < a.B) {
+        const int C = a.C;
+        const float* z = a.logits + (long)b * C;
+        float p[64], q[64], w[64];
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - mx); s += p[c]; }
+        for (int c = 0; c < C; ++c) p[c] /= s;
+        // second softmax over p (values in [0,1], no max shift needed but keep it)
+        float s2 = 0.f;
+        for (int c = 0; c < C; ++c) { q[c] = expf(p[c]); s2 += q[c]; }
+        const float lse2 = logf(s2);
+        for (int c = 0; c < C; ++c) q[c] /= s2;
+        const int t = (int)a.target[b];
+        const float sm = a.smoothing;
+        float smooth = 0.f;
+        for (int c = 0; c < C; ++c) smooth += -(p[c] - lse2);
+        smooth /= C;
+        const float nll = -(p[t] - lse2);
+        l = (1.0f - sm) * nll + sm * smooth;
+        // dl/dp_c = q_c - [(1-s) 1{c=t} + s/C]
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) { w[c] = q[c] - ((c == t ? 1.0f - sm : 0.f) + sm / C); dot += w[c] * p[c]; }
+        for (int c = 0; c < C; ++c) a.dlogits[(long)b * C + c] = p[c] * (w[c] - dot) / a.B;
+        if (a.prob) for (int c = 0; c < C; ++c) a.prob[(long)b * C + c] = p[c];
+    }
+    red[threadIdx.x] = l;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(a.loss, red[0] / a.B);
+}
+
+}  // namespace
+
+extern "C" int gv_cls_rows(const gv_cls_rows_args* a, void* stream) {
+    GV_REQUIRE(a && a->x && a->cls && a->pos, GV_E_NULL, "gv_cls_rows: null pointer");
+    GV_REQUIRE(a->n_img > 0 && a->N > 0 && a->D > 0, GV_E_SHAPE, "gv_cls_rows: bad shape");
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(a->n_img), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_cls_rows");
+    return GV_OK;
+}
+
+extern "C" int gv_tokens_bwd(const gv_tokens_bwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->g && a->gpatch && a->dpos, GV_E_NULL, "gv_tokens_bwd: null pointer");
+    GV_REQUIRE(a->n_img > 0 && a->N > 1 && a->D > 0, GV_E_SHAPE, "gv_tokens_bwd: bad shape");
+    hipLaunchKernelGGL(tokens_bwd_kernel, dim3(a->N, (a->D + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_tokens_bwd");
+    return GV_OK;
+}
+
+extern "C" int gv_small_matmul(const gv_small_matmul_args* a, void* stream) {
+    GV_REQUIRE(a && a->A && a->B && a->C, GV_E_NULL, "gv_small_matmul: null pointer");
+    GV_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->M < 65536, GV_E_SHAPE, "gv_small_matmul: bad shape");
+    hipLaunchKernelGGL(small_matmul_kernel, dim3((a->N + 127) / 128, a->M), dim3(128), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_small_matmul");
+    return GV_OK;
+}
+
+#define GV_ROW_LAUNCH(kern, a, name)                                                             \
+    GV_REQUIRE((a)->rows > 0 && (a)->C > 0 && (a)->C % 4 == 0, GV_E_SHAPE, name ": C must be a positive multiple of 4"); \
+    hipLaunchKernelGGL(kern, dim3(((a)->rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, *(a)); \
+    GV_LAUNCH_CHECK(name);                                                                       \
+    return GV_OK;
+
+extern "C" int gv_l2norm_fwd(const gv_l2norm_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->x && a->y && a->inv_norm, GV_E_NULL, "gv_l2norm_fwd: null pointer");
+    GV_ROW_LAUNCH(l2norm_fwd_kernel, a, "gv_l2norm_fwd")
+}
+extern "C" int gv_l2norm_bwd(const gv_l2norm_bwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->dy && a->y && a->inv_norm && a->dx, GV_E_NULL, "gv_l2norm_bwd: null pointer");
+    GV_ROW_LAUNCH(l2norm_bwd_kernel, a, "gv_l2norm_bwd")
+}
+extern "C" int gv_weightnorm_fwd(const gv_weightnorm_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->v && a->g && a->w, GV_E_NULL, "gv_weightnorm_fwd: null pointer");
+    GV_ROW_LAUNCH(weightnorm_fwd_kernel, a, "gv_weightnorm_fwd")
+}
+extern "C" int gv_weightnorm_bwd(const gv_weightnorm_bwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->dw && a->v && a->g && a->dv, GV_E_NULL, "gv_weightnorm_bwd: null pointer");
+    GV_ROW_LAUNCH(weightnorm_bwd_kernel, a, "gv_weightnorm_bwd")
+}
+
+extern "C" int gv_gather_cls(const gv_gather_cls_args* a, void* stream) {
+    GV_REQUIRE(a && a->x && a->y, GV_E_NULL, "gv_gather_cls: null pointer");
+    GV_REQUIRE(a->n_img > 0 && a->N > 0 && a->D > 0, GV_E_SHAPE, "gv_gather_cls: bad shape");
+    hipLaunchKernelGGL(gather_cls_kernel, dim3(a->n_img), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_gather_cls");
+    return GV_OK;
+}
+
+extern "C" int gv_cast_bf16(const gv_cast_bf16_args* a, void* stream) {
+    GV_REQUIRE(a && a->src && a->dst, GV_E_NULL, "gv_cast_bf16: null pointer");
+    GV_REQUIRE(a->n > 0, GV_E_SHAPE, "gv_cast_bf16: n must be > 0");
+    GV_REQUIRE(gv_aligned(a->src, 16) && gv_aligned(a->dst, 8), GV_E_ALIGN, "gv_cast_bf16: misaligned");
+    long blocks = (a->n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_cast_bf16");
+    return GV_OK;
+}
+
+extern "C" int gv_sumsq(const gv_sumsq_args* a, void* stream) {
+    GV_REQUIRE(a && a->x && a->workspace && a->out, GV_E_NULL, "gv_sumsq: null pointer");
+    GV_REQUIRE(a->n > 0 && gv_aligned(a->x, 16), GV_E_ALIGN, "gv_sumsq: x must be 16-byte aligned, n > 0");
+    long blocks = (a->n / 4 + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_sumsq");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a->workspace, (int)blocks, a->out, a->accumulate);
+    GV_LAUNCH_CHECK("gv_sumsq(final)");
+    return GV_OK;
+}
+
+extern "C" int gv_center_update(const gv_center_update_args* a, void* stream) {
+    GV_REQUIRE(a && a->center && a->center_sum, GV_E_NULL, "gv_center_update: null pointer");
+    GV_REQUIRE(a->K > 0, GV_E_SHAPE, "gv_center_update: K must be > 0");
+    hipLaunchKernelGGL(center_update_kernel, dim3((a->K + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_center_update");
+    return GV_OK;
+}
+
+extern "C" int gv_softmax_lsce(const gv_softmax_lsce_args* a, void* stream) {
+    GV_REQUIRE(a && a->logits && a->target && a->loss && a->dlogits, GV_E_NULL, "gv_softmax_lsce: null pointer");
+    GV_REQUIRE(a->B > 0 && a->C > 0 && a->C <= 64, GV_E_SHAPE, "gv_softmax_lsce: need 0 < C <= 64");
+    hipError_t e = hipMemsetAsync(a->loss, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) GV_FAIL((int)e, "gv_softmax_lsce: memset failed");
+    hipLaunchKernelGGL(softmax_lsce_kernel, dim3((a->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_softmax_lsce");
+    return GV_OK;
+}

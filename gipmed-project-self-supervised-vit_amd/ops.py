@@ -1,0 +1,179 @@
+"""Tensor-level wrappers over the C ABI: pass ``tensor.data_ptr()`` + the current
+HIP stream.  PyTorch is plumbing here (device memory, streams); all arithmetic
+runs in libgipvit_hip.so.  Every function launches asynchronously."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_cuda:
+        raise TypeError(f"{name}: expected a {dtype} device tensor, got {t.dtype} on {t.device}")
+
+
+def patchify(tiles_u8: torch.Tensor, windows: Sequence[Sequence[int]], crop: int, mean, std,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tiles_u8 [n_tiles, H, W, 3] u8 NHWC; windows [(y0, x0)] of side ``crop``.
+    Returns bf16 patches [(len(windows) * n_tiles) * (crop/16)^2, 768], images crop-major."""
+    _chk(tiles_u8, torch.uint8, "tiles")
+    assert tiles_u8.dim() == 4 and tiles_u8.shape[-1] == 3 and tiles_u8.is_contiguous()
+    n_tiles, H, W, _ = tiles_u8.shape
+    n_img = n_tiles * len(windows)
+    P = (crop // 16) ** 2
+    if out is None:
+        out = torch.empty(n_img * P, 768, dtype=bf16, device=tiles_u8.device)
+    a = L.gv_patchify_args()
+    a.tiles, a.patches, a.n_img, a.tile_h, a.tile_w = tiles_u8.data_ptr(), out.data_ptr(), n_img, H, W
+    a.img_stride, a.n_win, a.crop, a.n_tiles = H * W * 3, len(windows), crop, n_tiles
+    for i, (y, x) in enumerate(windows):
+        a.win_y[i], a.win_x[i] = int(y), int(x)
+    for c in range(3):
+        a.mean[c], a.std[c] = float(mean[c]), float(std[c])
+    L.call("gv_patchify", a, _stream())
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, rows: int, D: int, x_stride: Optional[int] = None, eps: float = 1e-6,
+                  y=None, mean=None, rstd=None):
+    _chk(x, f32, "x")
+    dev = x.device
+    y = torch.empty(rows, D, dtype=bf16, device=dev) if y is None else y
+    mean = torch.empty(rows, dtype=f32, device=dev) if mean is None else mean
+    rstd = torch.empty(rows, dtype=f32, device=dev) if rstd is None else rstd
+    a = L.gv_layernorm_fwd_args(x.data_ptr(), D if x_stride is None else x_stride, gamma.data_ptr(), beta.data_ptr(),
+                                y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, eps)
+    L.call("gv_layernorm_fwd", a, _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, g, gb, partials, rows: int, D: int, x_stride=None, g_stride=None,
+                  gb_stride=None, g_init: bool = False):
+    a = L.gv_layernorm_bwd_args(dy.data_ptr(), x.data_ptr(), D if x_stride is None else x_stride, mean.data_ptr(),
+                                rstd.data_ptr(), gamma.data_ptr(), g.data_ptr(), D if g_stride is None else g_stride,
+                                _p(gb), D if gb_stride is None else gb_stride, partials.data_ptr(), rows, D, int(g_init))
+    L.call("gv_layernorm_bwd", a, _stream())
+
+
+def colsum_finalize(partials, n_blocks: int, n_which: int, which: int, C: int, out, accumulate: bool):
+    a = L.gv_colsum_finalize_args(partials.data_ptr(), n_blocks, n_which, which, C, out.data_ptr(), int(accumulate))
+    L.call("gv_colsum_finalize", a, _stream())
+
+
+def colsum(x, rows: int, C: int, workspace, out, accumulate: bool = False, ld: Optional[int] = None):
+    a = L.gv_colsum_args(x.data_ptr(), int(x.dtype == f32), C if ld is None else ld, rows, C, workspace.data_ptr(),
+                         out.data_ptr(), int(accumulate))
+    L.call("gv_colsum", a, _stream())
+
+
+def linear(A, B, C, M: int, N: int, K: int, *, trans_a=False, trans_b=False, epilogue=0, bias=None, resid=None,
+           aux_in=None, aux_out=None, pos=None, P=0, alpha=1.0, lda=None, ldb=None, ldc=None, ldr=None, ld_aux=None):
+    """C[M,N] = op(A) op(B) (+ epilogue); see include/gipvit.h gv_linear."""
+    a = L.gv_linear_args()
+    a.A, a.B, a.C, a.M, a.N, a.K = A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K
+    a.lda = (M if trans_a else K) if lda is None else lda
+    a.ldb = (N if trans_b else K) if ldb is None else ldb
+    a.ldc = N if ldc is None else ldc
+    a.trans_a, a.trans_b, a.c_is_f32, a.epilogue = int(trans_a), int(trans_b), int(C.dtype == f32), epilogue
+    a.bias, a.resid, a.ldr = _p(bias), _p(resid), (N if ldr is None else ldr)
+    a.aux_in, a.ld_aux, a.aux_out = _p(aux_in), (N if ld_aux is None else ld_aux), _p(aux_out)
+    a.pos, a.P, a.alpha = _p(pos), P, alpha
+    L.call("gv_linear", a, _stream())
+    return C
+
+
+def attention_fwd(qkv, n_img: int, N: int, H: int, scale: float, o=None, lse=None):
+    dev = qkv.device
+    o = torch.empty(n_img * N, H * 64, dtype=bf16, device=dev) if o is None else o
+    lse = torch.empty(n_img, H, N, dtype=f32, device=dev) if lse is None else lse
+    a = L.gv_attention_fwd_args(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), n_img, N, H, scale)
+    L.call("gv_attention_fwd", a, _stream())
+    return o, lse
+
+
+def attention_bwd(qkv, o, d_o, lse, n_img: int, N: int, H: int, scale: float, dqkv=None):
+    dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
+    a = L.gv_attention_bwd_args(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), n_img, N, H, scale)
+    L.call("gv_attention_bwd", a, _stream())
+    return dqkv
+
+
+def cls_rows(x, cls, pos, n_img: int, N: int, D: int):
+    L.call("gv_cls_rows", L.gv_cls_rows_args(x.data_ptr(), cls.data_ptr(), pos.data_ptr(), n_img, N, D), _stream())
+
+
+def tokens_bwd(g, gpatch, dpos, dcls, n_img: int, N: int, D: int, accumulate: bool):
+    a = L.gv_tokens_bwd_args(g.data_ptr(), gpatch.data_ptr(), dpos.data_ptr(), _p(dcls), n_img, N, D, int(accumulate))
+    L.call("gv_tokens_bwd", a, _stream())
+
+
+def small_matmul(A, B, C, M: int, N: int, K: int, trans_a=False, accumulate=False):
+    a = L.gv_small_matmul_args(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, int(trans_a), int(accumulate))
+    L.call("gv_small_matmul", a, _stream())
+
+
+def l2norm_fwd(x, y, inv_norm, rows: int, C: int):
+    L.call("gv_l2norm_fwd", L.gv_l2norm_fwd_args(x.data_ptr(), y.data_ptr(), inv_norm.data_ptr(), rows, C), _stream())
+
+
+def l2norm_bwd(dy, y, inv_norm, dx, rows: int, C: int):
+    L.call("gv_l2norm_bwd", L.gv_l2norm_bwd_args(dy.data_ptr(), y.data_ptr(), inv_norm.data_ptr(), dx.data_ptr(), rows, C), _stream())
+
+
+def weightnorm_fwd(v, g, w, rows: int, C: int):
+    L.call("gv_weightnorm_fwd", L.gv_weightnorm_fwd_args(v.data_ptr(), g.data_ptr(), w.data_ptr(), rows, C), _stream())
+
+
+def weightnorm_bwd(dw, v, g, dv, dg, rows: int, C: int, accumulate: bool):
+    a = L.gv_weightnorm_bwd_args(dw.data_ptr(), v.data_ptr(), g.data_ptr(), dv.data_ptr(), _p(dg), rows, C, int(accumulate))
+    L.call("gv_weightnorm_bwd", a, _stream())
+
+
+def dino_loss(student, teacher, center, dstudent, loss, center_sum, workspace, B: int, V: int, G: int, K: int,
+              student_temp: float, teacher_temp: float, grad_scale: float = 1.0):
+    a = L.gv_dino_loss_args(student.data_ptr(), teacher.data_ptr(), center.data_ptr(), dstudent.data_ptr(), loss.data_ptr(),
+                            center_sum.data_ptr(), workspace.data_ptr(), B, V, G, K, student_temp, teacher_temp, grad_scale)
+    L.call("gv_dino_loss", a, _stream())
+
+
+def center_update(center, center_sum, K: int, momentum: float, inv_rows: float):
+    L.call("gv_center_update", L.gv_center_update_args(center.data_ptr(), center_sum.data_ptr(), K, momentum, inv_rows), _stream())
+
+
+def softmax_lsce(logits, target, loss, dlogits, prob, B: int, C: int, smoothing: float):
+    a = L.gv_softmax_lsce_args(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), dlogits.data_ptr(), _p(prob), B, C, smoothing)
+    L.call("gv_softmax_lsce", a, _stream())
+
+
+def gather_cls(x, y, n_img: int, N: int, D: int):
+    L.call("gv_gather_cls", L.gv_gather_cls_args(x.data_ptr(), y.data_ptr(), n_img, N, D), _stream())
+
+
+def cast_bf16(src, dst, n: Optional[int] = None):
+    L.call("gv_cast_bf16", L.gv_cast_bf16_args(src.data_ptr(), dst.data_ptr(), src.numel() if n is None else n), _stream())
+
+
+def sumsq(x, workspace, out, accumulate: bool = False, n: Optional[int] = None):
+    a = L.gv_sumsq_args(x.data_ptr(), x.numel() if n is None else n, workspace.data_ptr(), out.data_ptr(), int(accumulate))
+    L.call("gv_sumsq", a, _stream())
+
+
+def adamw_ema(p, grad, m, v, p_bf16, teacher, teacher_bf16, n: int, *, lr, beta1, beta2, eps, weight_decay, step: int,
+              grad_scale=1.0, clip_norm=0.0, gnorm_sq=None, teacher_momentum=0.0):
+    a = L.gv_adamw_ema_args(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), _p(teacher), _p(teacher_bf16), n,
+                            lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
+                            grad_scale, clip_norm, _p(gnorm_sq), teacher_momentum)
+    L.call("gv_adamw_ema", a, _stream())

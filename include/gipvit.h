@@ -1,0 +1,255 @@
+/*
+ * gipvit.h -- C ABI of libgipvit_hip.so: the MI355X (gfx950) implementation of the
+ * ViT-encoder + DINO multi-crop training hot path of
+ * noam-mosh/GipMed-Project-Self-Supervised-ViT.
+ *
+ * The reference has no FFI of its own for this path: the arithmetic is reached
+ * through ATen library calls issued by timm's VisionTransformer
+ * (reference train.py:482-495 create_model, train.py:1044-1078 step) and by the
+ * orphaned nn_encoder_arch ViT / DINOHead bytecode (cited
+ * below as vit.pyc@L<n>).  Each entry point names the reference call it replaces.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (tensor.data_ptr());
+ *     the library allocates nothing, keeps no reference after return, and only
+ *     enqueues kernels on `stream` (a hipStream_t passed as void*); it never
+ *     synchronises, so every call is hipGraph-capturable;
+ *   - return 0 on success, <0 = GV_E_* argument error (message in
+ *     gv_last_error(), thread local), >0 = hipError_t of a failed launch;
+ *   - "bf16" buffers hold bfloat16 bit patterns (uint16_t), "f32" IEEE float;
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
+ */
+#ifndef GIPVIT_H
+#define GIPVIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GV_ABI_VERSION 1
+
+enum {
+    GV_OK = 0,
+    GV_E_SHAPE = -1,      /* unsupported / inconsistent shape            */
+    GV_E_ALIGN = -2,      /* pointer or leading dimension misaligned     */
+    GV_E_NULL = -3,       /* required pointer is NULL                    */
+    GV_E_UNSUPPORTED = -4 /* flag / dtype combination not built          */
+};
+
+/* ---- library ---------------------------------------------------------- */
+int gv_version(void);
+const char* gv_last_error(void);
+/* name of the gfx target the kernels were compiled for ("gfx950") */
+const char* gv_target(void);
+
+/* ---- patchify: replaces PatchEmbed's Conv2d im2col on the reference input
+ * contract (vit.pyc@L167-170; datasets.py:614-631 -> transformations.py:124-128
+ * ToTensor + Normalize).  Reads crop windows of NHWC uint8 tiles, applies
+ * (u8/255 - mean[c]) / std[c] and writes bf16 patch rows [n_img*P, 768] with
+ * k = c*256 + py*16 + px (the flatten order of Conv2d weight [D,3,16,16]). */
+typedef struct {
+    const uint8_t* tiles; /* [n_img, tile_h, tile_w, 3] u8 (NHWC)             */
+    void* patches;        /* bf16 [n_img * (crop/16)^2, 768]                  */
+    int32_t n_img;        /* images in this crop group                        */
+    int32_t tile_h, tile_w;
+    int64_t img_stride;   /* bytes between consecutive images                 */
+    int32_t n_win;        /* crop windows per tile (images = tiles x windows) */
+    int32_t win_y[16], win_x[16]; /* window origin per window index           */
+    int32_t crop;         /* window side, multiple of 16                      */
+    float mean[3], std[3];
+    /* image index i -> tile i % n_tiles, window i / n_tiles (crop-major)     */
+    int32_t n_tiles;
+} gv_patchify_args;
+int gv_patchify(const gv_patchify_args* a, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm(D, eps=1e-6); vit.pyc@L138,142,195) -------
+ * fwd: x f32 rows -> y bf16 rows (+ mean, rstd f32 per row).
+ * D must be 192, 384 or 768.  Row r of x lives at x + r*x_stride.        */
+typedef struct {
+    const float* x; int64_t x_stride;
+    const float* gamma; const float* beta;
+    void* y;              /* bf16 [rows, D] compact                         */
+    float* mean; float* rstd; /* [rows]                                      */
+    int32_t rows, D; float eps;
+} gv_layernorm_fwd_args;
+int gv_layernorm_fwd(const gv_layernorm_fwd_args* a, void* stream);
+
+/* bwd: g[r] (f32, the residual-stream gradient, stride g_stride) += dLN/dx;
+ * gb[r] = bf16(g[r]); partial column sums of dy*xhat, dy and new g are left
+ * in `partials` [GV_LN_PARTIAL_BLOCKS, 3, D] f32 for gv_colsum_finalize.   */
+#define GV_LN_PARTIAL_BLOCKS 512
+typedef struct {
+    const void* dy;       /* bf16 [rows, D] compact                         */
+    const float* x; int64_t x_stride;
+    const float* mean; const float* rstd; const float* gamma;
+    float* g; int64_t g_stride;   /* in/out                                  */
+    void* gb; int64_t gb_stride;  /* bf16 out (may be NULL)                  */
+    float* partials;
+    int32_t rows, D;
+    int32_t g_init;       /* 1: g is treated as 0 on input (g = dx)          */
+} gv_layernorm_bwd_args;
+int gv_layernorm_bwd(const gv_layernorm_bwd_args* a, void* stream);
+
+/* out[c] (+)= sum_b partials[b, which, c] for b < n_blocks                 */
+typedef struct {
+    const float* partials; int32_t n_blocks, n_which, which, C;
+    float* out; int32_t accumulate;
+} gv_colsum_finalize_args;
+int gv_colsum_finalize(const gv_colsum_finalize_args* a, void* stream);
+
+/* column sums of a bf16 or f32 matrix [rows, C] -> out[C] f32 (bias grads,
+ * train.py:1071 backward of nn.Linear bias).  workspace >= 64*C floats.    */
+typedef struct {
+    const void* x; int32_t x_is_f32; int64_t ld;
+    int32_t rows, C;
+    float* workspace; float* out; int32_t accumulate;
+} gv_colsum_args;
+int gv_colsum(const gv_colsum_args* a, void* stream);
+
+/* ---- linear / GEMM (nn.Linear fwd + both backward products; vit.pyc@L98-104,
+ * L119-131, L326-330).  C[M,N] = op(A) . op(B) with bf16 operands, f32 MFMA
+ * accumulation (v_mfma_f32_16x16x32_bf16):
+ *    trans_a = 0: A stored [M,K];  1: A stored [K,M]
+ *    trans_b = 0: B stored [N,K] (torch Linear weight);  1: B stored [K,N]
+ * forward  y = x W^T      : (0,0)        dX = dY W : (0,1)     dW = dY^T X : (1,1)
+ * Epilogue, applied in this order to the f32 accumulator v at (m,n):
+ *    BIAS: v += bias[n];  SAVE_PRE: aux_out[m,n] = bf16(v);  GELU: v = gelu(v);
+ *    DGELU: v *= gelu'(aux_in[m,n]);  RESID: v += resid[m,n] (f32);
+ *    POS: token-row remap m -> m + m/P + 1 and v += pos[(m%P)+1, n] (patch embed);
+ *    ACCUM: v += C[m,n] (f32 out only);  then C[m,n] = v (bf16 or f32).       */
+enum {
+    GV_EPI_BIAS = 1, GV_EPI_GELU = 2, GV_EPI_RESID = 4, GV_EPI_DGELU = 8,
+    GV_EPI_ACCUM = 16, GV_EPI_POS = 32, GV_EPI_SAVE_PRE = 64
+};
+typedef struct {
+    const void* A; const void* B; void* C;
+    int32_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int32_t trans_a, trans_b;
+    int32_t c_is_f32;
+    int32_t epilogue;           /* GV_EPI_* bitmask                          */
+    const float* bias;          /* [N] f32                                   */
+    const float* resid; int64_t ldr;   /* f32 [M,N]                          */
+    const void* aux_in; int64_t ld_aux; /* bf16 [M,N] pre-activation (DGELU) */
+    void* aux_out;              /* bf16 [M,N], ld = ld_aux (SAVE_PRE)        */
+    const float* pos; int32_t P; /* POS: pos f32 [(P+1), N]                  */
+    float alpha;                /* scales the accumulator before the epilogue*/
+} gv_linear_args;
+int gv_linear(const gv_linear_args* a, void* stream);
+
+/* ---- attention (vit.pyc@L119-131): softmax(q k^T * scale) v per (image, head)
+ * on packed qkv bf16 [n_img*N, 3, H, 64] -> o bf16 [n_img*N, H, 64];
+ * lse f32 [n_img, H, N] (natural-log sum-exp of the scaled scores).
+ * head_dim is fixed at 64 (ViT-T/S/B); N <= 288.                            */
+typedef struct {
+    const void* qkv; void* o; float* lse;
+    int32_t n_img, N, H; float scale;
+} gv_attention_fwd_args;
+int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream);
+
+typedef struct {
+    const void* qkv; const void* o; const void* d_o; const float* lse;
+    void* dqkv;           /* bf16 [n_img*N, 3, H, 64]                        */
+    int32_t n_img, N, H; float scale;
+} gv_attention_bwd_args;
+int gv_attention_bwd(const gv_attention_bwd_args* a, void* stream);
+
+/* ---- token assembly (vit.pyc@L235-246 prepare_tokens: CLS row) ---------
+ * x[i*N + 0, :] = cls[:] + pos[0, :] for every image i.                    */
+typedef struct { float* x; const float* cls; const float* pos; int32_t n_img, N, D; } gv_cls_rows_args;
+int gv_cls_rows(const gv_cls_rows_args* a, void* stream);
+
+/* backward of token assembly: from g f32 [n_img*N, D] produce
+ *   gpatch bf16 [n_img*P, D] (compact patch rows, A operand of dW_patch),
+ *   dpos f32 [N, D] (+)= sum_i g[i*N + t]  (dcls = dpos row 0 before the add
+ *   is also written to dcls (+)=).                                           */
+typedef struct {
+    const float* g; void* gpatch; float* dpos; float* dcls;
+    int32_t n_img, N, D; int32_t accumulate;
+} gv_tokens_bwd_args;
+int gv_tokens_bwd(const gv_tokens_bwd_args* a, void* stream);
+
+/* small f32 matmul C[M,N] (+)= A[M,K] B[K,N] (bicubic pos-embed resampling,
+ * vit.pyc@L213-233, expressed as a fixed linear map; trans_a uses A^T).     */
+typedef struct {
+    const float* A; const float* B; float* C; int32_t M, N, K; int32_t trans_a; int32_t accumulate;
+} gv_small_matmul_args;
+int gv_small_matmul(const gv_small_matmul_args* a, void* stream);
+
+/* ---- DINOHead tail (vit.pyc@L326-330) ---------------------------------
+ * l2norm fwd: y bf16 = x / max(||x||, 1e-12), inv_norm f32 [rows] saved.    */
+typedef struct { const float* x; void* y; float* inv_norm; int32_t rows, C; } gv_l2norm_fwd_args;
+int gv_l2norm_fwd(const gv_l2norm_fwd_args* a, void* stream);
+/* bwd: dx bf16 = (dy - y (y.dy)) * inv_norm  (dy f32, y bf16)               */
+typedef struct { const float* dy; const void* y; const float* inv_norm; void* dx; int32_t rows, C; } gv_l2norm_bwd_args;
+int gv_l2norm_bwd(const gv_l2norm_bwd_args* a, void* stream);
+/* weight_norm: w bf16 [K,C] = g[k] * v[k,:] / ||v[k,:]||                    */
+typedef struct { const float* v; const float* g; void* w; int32_t rows, C; } gv_weightnorm_fwd_args;
+int gv_weightnorm_fwd(const gv_weightnorm_fwd_args* a, void* stream);
+/* bwd: dv (+)= g/||v|| (dw - vhat (vhat.dw)); dg (+)= vhat.dw (dg may be NULL) */
+typedef struct {
+    const float* dw; const float* v; const float* g; float* dv; float* dg;
+    int32_t rows, C; int32_t accumulate;
+} gv_weightnorm_bwd_args;
+int gv_weightnorm_bwd(const gv_weightnorm_bwd_args* a, void* stream);
+
+/* ---- DINO loss (paper Alg. 1; absent from the reference)
+ * student f32 [V*B, K] crop-major, teacher f32 [G*B, K] crop-major.
+ * Writes loss (scalar f32, mean over the G*(V-1)... pairs and B), dstudent
+ * bf16 [V*B, K] = d loss / d student * grad_scale, and center_sum f32 [K] =
+ * sum over teacher rows of the raw teacher logits.
+ * workspace: f32 [2 * (V+G) * B] row stats.                                 */
+typedef struct {
+    const float* student; const float* teacher; const float* center;
+    void* dstudent; float* loss; float* center_sum; float* workspace;
+    int32_t B, V, G, K;
+    float student_temp, teacher_temp, grad_scale;
+} gv_dino_loss_args;
+int gv_dino_loss(const gv_dino_loss_args* a, void* stream);
+
+/* center <- m * center + (1-m) * center_sum / n_rows (after the all-reduce) */
+typedef struct { float* center; const float* center_sum; int32_t K; float momentum; float inv_rows; } gv_center_update_args;
+int gv_center_update(const gv_center_update_args* a, void* stream);
+
+/* ---- supervised head loss (train.py:1046 softmax, :1053 LabelSmoothingCE on
+ * the soft-maxed output, gather index target[B,1] per train_instruct.txt:3-7).
+ * logits f32 [B,C] (C <= 64), target i64 [B]; loss scalar; dlogits f32 [B,C].*/
+typedef struct {
+    const float* logits; const int64_t* target; float* loss; float* dlogits; float* prob;
+    int32_t B, C; float smoothing;
+} gv_softmax_lsce_args;
+int gv_softmax_lsce(const gv_softmax_lsce_args* a, void* stream);
+
+/* ---- gather / scatter of CLS rows: y[i,:] = x[i*N, :] (f32 -> bf16) -------*/
+typedef struct { const float* x; void* y; int32_t n_img, N, D; } gv_gather_cls_args;
+int gv_gather_cls(const gv_gather_cls_args* a, void* stream);
+
+/* f32 -> bf16 cast of a flat buffer (weight arena refresh)                  */
+typedef struct { const float* src; void* dst; int64_t n; } gv_cast_bf16_args;
+int gv_cast_bf16(const gv_cast_bf16_args* a, void* stream);
+
+/* sum of squares of a flat f32 buffer -> out[0] (+)= ; workspace >= 1024 f32 */
+typedef struct { const float* x; int64_t n; float* workspace; float* out; int32_t accumulate; } gv_sumsq_args;
+int gv_sumsq(const gv_sumsq_args* a, void* stream);
+
+/* ---- fused AdamW + teacher EMA + bf16 refresh over a flat parameter arena
+ * (train.py:1078 optimizer.step; :1080-1081 model_ema.update).
+ *   if clip_norm > 0: scale = min(1, clip_norm / (sqrt(*gnorm_sq) + 1e-6))
+ *   g = grad * grad_scale * scale;  p *= 1 - lr*wd;  m,v Adam;  p -= ...
+ *   p_bf16 = bf16(p);  if teacher: t = mom*t + (1-mom)*p; t_bf16 = bf16(t)   */
+typedef struct {
+    float* p; const float* grad; float* m; float* v; void* p_bf16;
+    float* teacher; void* teacher_bf16;
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2;
+    float grad_scale, clip_norm; const float* gnorm_sq;
+    float teacher_momentum;
+} gv_adamw_ema_args;
+int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIPVIT_H */

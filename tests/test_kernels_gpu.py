@@ -1,0 +1,366 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch fp32 reference of
+the same op on the same (bf16-rounded) inputs.  Tolerances are stated per test; integer
+data is used where the result must be bit exact (GEMM operand layouts)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+def ops():
+    from gipvit import ops as o
+    return o
+
+
+def L():
+    from gipvit import _lib
+    return _lib
+
+
+def close(got, ref, rtol, atol, what=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} (ref max {float(ref.abs().max()):.4g})"
+
+
+def ints(shape, dev, lo=-2, hi=3, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).to(dev).to(bf16)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (197 * 2, 1152, 384), (100, 72, 192), (37 * 8, 1536, 384),
+                                   (130, 8, 128)])
+def test_linear_nt_exact(dev, M, N, K):
+    A, B = ints((M, K), dev, seed=1), ints((N, K), dev, seed=2)
+    C = torch.full((M, N), 7.0, dtype=f32, device=dev)
+    ops().linear(A, B, C, M, N, K)
+    assert torch.equal(C, A.float() @ B.float().t())
+    Cb = torch.empty(M, N, dtype=bf16, device=dev)
+    ops().linear(A, B, Cb, M, N, K)
+    assert torch.equal(Cb.float(), (A.float() @ B.float().t()).to(bf16).float())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (394, 384, 1152), (300, 192, 576 + 64), (256, 768, 128)])
+def test_linear_nn_exact(dev, M, N, K):
+    """dX = dY W : A [M,K] k-contiguous, B stored [K,N]."""
+    A, B = ints((M, K), dev, seed=3), ints((K, N), dev, seed=4)
+    C = torch.empty(M, N, dtype=f32, device=dev)
+    ops().linear(A, B, C, M, N, K, trans_b=True)
+    assert torch.equal(C, A.float() @ B.float())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (384, 1152, 394), (1536, 384, 1000), (192, 576, 37 * 8 + 5), (256, 256, 8192)])
+def test_linear_tn_exact(dev, M, N, K):
+    """dW = dY^T X : A stored [K,M], B stored [K,N]; K = tokens (any length)."""
+    A, B = ints((K, M), dev, -1, 2, seed=5), ints((K, N), dev, -1, 2, seed=6)
+    ref = A.float().t() @ B.float()
+    C = torch.empty(M, N, dtype=f32, device=dev)
+    ops().linear(A, B, C, M, N, K, trans_a=True, trans_b=True)
+    assert torch.equal(C, ref)
+    # ACCUM (+ split-K with f32 atomics when the grid is small): integers stay exact
+    C2 = torch.ones(M, N, dtype=f32, device=dev)
+    ops().linear(A, B, C2, M, N, K, trans_a=True, trans_b=True, epilogue=L().EPI_ACCUM)
+    assert torch.equal(C2, ref + 1.0)
+
+
+def test_linear_epilogues(dev):
+    o, l = ops(), L()
+    M, N, K = 394, 1536, 384
+    g = torch.Generator().manual_seed(7)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(bf16)
+    B = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(bf16)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    ref = A.float() @ B.float().t() + bias
+    # bias + save_pre + gelu
+    C = torch.empty(M, N, dtype=bf16, device=dev); pre = torch.empty(M, N, dtype=bf16, device=dev)
+    o.linear(A, B, C, M, N, K, epilogue=l.EPI_BIAS | l.EPI_GELU | l.EPI_SAVE_PRE, bias=bias, aux_out=pre)
+    close(pre, ref, 1e-2, 1e-2, "pre")
+    close(C, torch.nn.functional.gelu(ref), 1e-2, 1e-2, "gelu")
+    # bias + resid, f32 out
+    Cf = torch.empty(M, N, dtype=f32, device=dev)
+    o.linear(A, B, Cf, M, N, K, epilogue=l.EPI_BIAS | l.EPI_RESID, bias=bias, resid=resid)
+    close(Cf, ref + resid, 1e-4, 1e-4, "resid")
+    # dgelu: v * gelu'(aux)
+    aux = torch.randn(M, N, generator=g).to(dev).to(bf16)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    o.linear(A, B, C, M, N, K, epilogue=l.EPI_DGELU, aux_in=aux)
+    close(C, (A.float() @ B.float().t()) * x.grad, 1e-2, 1e-2, "dgelu")
+    # alpha
+    o.linear(A, B, Cf, M, N, K, alpha=0.25)
+    close(Cf, 0.25 * (A.float() @ B.float().t()), 1e-4, 1e-4, "alpha")
+
+
+def test_linear_pos_epilogue(dev):
+    """patch-embed epilogue: rows remapped past the CLS slot, pos-embed added."""
+    o, l = ops(), L()
+    n_img, P, D, K = 3, 36, 384, 768
+    M = n_img * P
+    g = torch.Generator().manual_seed(8)
+    A = torch.randn(M, K, generator=g).to(dev).to(bf16)
+    W = (torch.randn(D, K, generator=g) * 0.03).to(dev).to(bf16)
+    bias = torch.randn(D, generator=g).to(dev); pos = torch.randn(P + 1, D, generator=g).to(dev)
+    x = torch.zeros(n_img * (P + 1), D, dtype=f32, device=dev)
+    o.linear(A, W, x, M, D, K, epilogue=l.EPI_BIAS | l.EPI_POS, bias=bias, pos=pos, P=P)
+    ref = (A.float() @ W.float().t() + bias).view(n_img, P, D) + pos[1:]
+    xv = x.view(n_img, P + 1, D)
+    close(xv[:, 1:], ref, 1e-4, 1e-3, "pos rows")
+    assert float(xv[:, 0].abs().max()) == 0.0
+
+
+def test_linear_rejects_bad_shapes(dev):
+    A = torch.zeros(64, 100, dtype=bf16, device=dev); B = torch.zeros(64, 100, dtype=bf16, device=dev)
+    C = torch.zeros(64, 64, dtype=f32, device=dev)
+    with pytest.raises(L().GipvitError, match="multiple of 64"):
+        ops().linear(A, B, C, 64, 64, 100, lda=104, ldb=104)
+
+
+# ------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("D", [192, 384, 768])
+def test_layernorm_fwd_bwd(dev, D):
+    o = ops()
+    rows = 1000 + 3
+    g = torch.Generator().manual_seed(D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev); beta = (0.1 * torch.randn(D, generator=g)).to(dev)
+    y, mean, rstd = o.layernorm_fwd(x, gamma, beta, rows, D)
+    ref = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-6)
+    close(y, ref, 8e-3, 8e-3, "ln fwd")           # bf16 output rounding
+    close(mean, x.mean(-1), 1e-5, 1e-5, "mean")
+    # backward: g += dLN/dx, gb = bf16(g), partial column sums
+    dy = torch.randn(rows, D, generator=g).to(dev).to(bf16)
+    g0 = torch.randn(rows, D, generator=g).to(dev)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy.float())
+    gbuf = g0.clone(); gb = torch.empty(rows, D, dtype=bf16, device=dev)
+    partials = torch.empty(L().LN_PARTIAL_BLOCKS, 3, D, dtype=f32, device=dev)
+    o.layernorm_bwd(dy, x, mean, rstd, gamma, gbuf, gb, partials, rows, D)
+    close(gbuf, g0 + xr.grad, 1e-4, 1e-4, "ln dx")
+    close(gb, g0 + xr.grad, 8e-3, 8e-3, "gb")
+    outs = [torch.zeros(D, device=dev) for _ in range(3)]
+    for w in range(3):
+        o.colsum_finalize(partials, L().LN_PARTIAL_BLOCKS, 3, w, D, outs[w], False)
+    close(outs[0], gr.grad, 1e-3, 1e-2, "dgamma")
+    close(outs[1], br.grad, 1e-3, 1e-2, "dbeta")
+    close(outs[2], (g0 + xr.grad).sum(0), 1e-3, 1e-2, "colsum g")
+    # strided rows + g_init (final norm on CLS rows)
+    N = 5; n_img = 40
+    xs = torch.randn(n_img * N, D, generator=g).to(dev)
+    y2, m2, r2 = o.layernorm_fwd(xs, gamma, beta, n_img, D, x_stride=N * D)
+    close(y2, torch.nn.functional.layer_norm(xs.view(n_img, N, D)[:, 0], (D,), gamma, beta, 1e-6), 8e-3, 8e-3, "ln strided")
+    gfull = torch.full((n_img * N, D), 3.0, device=dev)
+    dy2 = torch.randn(n_img, D, generator=g).to(dev).to(bf16)
+    o.layernorm_bwd(dy2, xs, m2, r2, gamma, gfull, None, partials, n_img, D, x_stride=N * D, g_stride=N * D, g_init=True)
+    xr2 = xs.view(n_img, N, D)[:, 0].clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr2, (D,), gamma, beta, 1e-6).backward(dy2.float())
+    gv = gfull.view(n_img, N, D)
+    close(gv[:, 0], xr2.grad, 1e-4, 1e-4, "ln dx strided")
+    assert float((gv[:, 1:] - 3.0).abs().max()) == 0.0
+
+
+def test_colsum(dev):
+    o = ops()
+    rows, C = 2051, 1152
+    x = torch.randn(rows, C, generator=torch.Generator().manual_seed(1)).to(dev)
+    ws = torch.empty(64 * C, device=dev); out = torch.ones(C, device=dev)
+    o.colsum(x.to(bf16), rows, C, ws, out, accumulate=True)
+    close(out, 1 + x.to(bf16).float().sum(0), 1e-4, 1e-2, "colsum bf16")
+    o.colsum(x, rows, C, ws, out, accumulate=False)
+    close(out, x.sum(0), 1e-4, 1e-3, "colsum f32")
+
+
+# ------------------------------------------------------------------------ attention
+def _attn_ref(qkv, n_img, N, H, scale):
+    q, k, v = qkv.float().view(n_img, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * scale
+    p = s.softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(n_img * N, H * 64)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("N,H,n_img", [(197, 6, 5), (37, 6, 7), (17, 3, 9), (257, 6, 2), (65, 12, 3), (1, 3, 2), (224, 2, 1)])
+def test_attention_fwd_bwd(dev, N, H, n_img):
+    o = ops()
+    g = torch.Generator().manual_seed(N * 7 + H)
+    qkv = torch.randn(n_img * N, 3 * H * 64, generator=g).to(dev).to(bf16)
+    scale = 64 ** -0.5
+    out, lse = o.attention_fwd(qkv, n_img, N, H, scale)
+    x = qkv.float().requires_grad_(True)
+    ref, ref_lse = _attn_ref(x, n_img, N, H, scale)
+    close(out, ref, 2e-2, 2e-2, "attn o")        # bf16 P and bf16 output
+    close(lse, ref_lse, 1e-3, 1e-3, "lse")
+    d_o = torch.randn(n_img * N, H * 64, generator=g).to(dev).to(bf16)
+    ref.backward(d_o.float())
+    dqkv = o.attention_bwd(qkv, out, d_o, lse, n_img, N, H, scale)
+    scale_ref = float(x.grad.abs().max())
+    close(dqkv, x.grad, 3e-2, 2e-2 * max(scale_ref, 1.0), "dqkv")
+
+
+def test_attention_softmax_spike(dev):
+    """one key dominating one query row: exercises the max-subtraction path (rule 26)."""
+    o = ops()
+    N, H, n_img = 197, 6, 2
+    qkv = (torch.randn(n_img * N, 3 * H * 64, generator=torch.Generator().manual_seed(3)) * 0.1).to(dev).to(bf16)
+    v = qkv.view(n_img, N, 3, H, 64)
+    v[0, 5, 0, 2] = 8.0; v[0, 100, 1, 2] = 8.0       # q row 5 . k row 100 = 64*64*scale = 512
+    out, lse = o.attention_fwd(qkv, n_img, N, H, 0.125)
+    ref, ref_lse = _attn_ref(qkv, n_img, N, H, 0.125)
+    assert bool(torch.isfinite(out.float()).all())
+    close(out, ref, 2e-2, 2e-2, "spike o")
+    close(lse, ref_lse, 1e-3, 1e-2, "spike lse")
+
+
+# ------------------------------------------------------------------------- patchify
+def test_patchify(dev):
+    o = ops()
+    g = torch.Generator().manual_seed(11)
+    tiles = torch.randint(0, 256, (3, 256, 256, 3), generator=g, dtype=torch.uint8).to(dev)
+    mean, std = (0.8998, 0.8253, 0.9357), (0.1125, 0.1751, 0.0787)
+    for crop, wins in ((224, [(0, 0), (16, 16)]), (96, [(20 * l, 160 - 20 * l) for l in range(8)]), (96, [(1, 3), (7, 157)])):
+        p = o.patchify(tiles, wins, crop, mean, std)
+        side = crop // 16
+        refs = []
+        for (y0, x0) in wins:
+            x = tiles[:, y0:y0 + crop, x0:x0 + crop, :].float() / 255.0
+            x = (x - torch.tensor(mean, device=dev)) / torch.tensor(std, device=dev)
+            x = x.permute(0, 3, 1, 2)                                   # [n,3,crop,crop]
+            x = x.reshape(3, 3, side, 16, side, 16).permute(0, 2, 4, 1, 3, 5)  # n, prow, pcol, c, py, px
+            refs.append(x.reshape(3 * side * side, 768))
+        close(p, torch.cat(refs), 4e-3, 4e-3, f"patchify {crop}")     # bf16 rounding only
+
+
+# -------------------------------------------------------------------- DINO head tail
+def test_l2norm_weightnorm(dev):
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    rows, C = 77, 256
+    x = torch.randn(rows, C, generator=g).to(dev)
+    y = torch.empty(rows, C, dtype=bf16, device=dev); inv = torch.empty(rows, device=dev)
+    o.l2norm_fwd(x, y, inv, rows, C)
+    close(y, torch.nn.functional.normalize(x, dim=-1), 8e-3, 1e-3, "l2norm")
+    dy = torch.randn(rows, C, generator=g).to(dev)
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.normalize(xr, dim=-1).backward(dy)
+    dx = torch.empty(rows, C, dtype=bf16, device=dev)
+    o.l2norm_bwd(dy, y, inv, dx, rows, C)
+    close(dx, xr.grad, 2e-2, 2e-3, "l2norm bwd")
+    K = 1000
+    v = torch.randn(K, C, generator=g).to(dev); gg = (1 + 0.1 * torch.randn(K, generator=g)).to(dev)
+    w = torch.empty(K, C, dtype=bf16, device=dev)
+    o.weightnorm_fwd(v, gg, w, K, C)
+    close(w, gg[:, None] * v / v.norm(dim=1, keepdim=True), 8e-3, 1e-3, "weightnorm")
+    dw = torch.randn(K, C, generator=g).to(dev)
+    vr = v.clone().requires_grad_(True); gr = gg.clone().requires_grad_(True)
+    (gr[:, None] * vr / vr.norm(dim=1, keepdim=True)).backward(dw)
+    dv = torch.ones(K, C, device=dev); dg = torch.zeros(K, device=dev)
+    o.weightnorm_bwd(dw, v, gg, dv, dg, K, C, accumulate=True)
+    close(dv, 1 + vr.grad, 1e-4, 1e-4, "dv")
+    close(dg, gr.grad, 1e-4, 1e-4, "dg")
+
+
+# ------------------------------------------------------------------------ DINO loss
+@pytest.mark.parametrize("B,V,G,K", [(4, 10, 2, 4096), (3, 4, 2, 256), (2, 2, 2, 65536), (5, 6, 1, 1024)])
+def test_dino_loss(dev, B, V, G, K):
+    from oracle import vit_oracle as vo
+    o = ops()
+    g = torch.Generator().manual_seed(B * 100 + V)
+    s = torch.randn(V * B, K, generator=g).to(dev); t = torch.randn(G * B, K, generator=g).to(dev)
+    center = (0.1 * torch.randn(1, K, generator=g)).to(dev)
+    sr = s.clone().requires_grad_(True)
+    loss_ref, csum_ref = vo.dino_loss(sr, t, center, V, G, 0.1, 0.04)
+    loss_ref.backward()
+    ds = torch.empty(V * B, K, dtype=bf16, device=dev); loss = torch.empty(1, device=dev)
+    csum = torch.empty(K, device=dev); ws = torch.empty(2 * (V + G) * B, device=dev)
+    o.dino_loss(s, t, center, ds, loss, csum, ws, B, V, G, K, 0.1, 0.04)
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref))), (float(loss), float(loss_ref))
+    close(csum, csum_ref[0], 1e-4, 1e-4, "center sum")
+    gmax = float(sr.grad.abs().max())
+    close(ds, sr.grad, 1e-2, 1e-2 * gmax, "dstudent")
+    c2 = center[0].clone()
+    o.center_update(c2, csum, K, 0.9, 1.0 / (G * B))
+    close(c2, vo.update_center(center, csum_ref, G * B, 0.9)[0], 1e-5, 1e-6, "center")
+
+
+def test_softmax_lsce(dev):
+    from oracle import vit_oracle as vo
+    o = ops()
+    for B, C in ((8, 2), (300, 5)):
+        g = torch.Generator().manual_seed(B)
+        z = torch.randn(B, C, generator=g).to(dev); tgt = torch.randint(0, C, (B, 1), generator=g).to(dev)
+        zr = z.clone().requires_grad_(True)
+        ref = vo.softmax_lsce(zr, tgt, 0.1); ref.backward()
+        loss = torch.empty(1, device=dev); dz = torch.empty(B, C, device=dev); prob = torch.empty(B, C, device=dev)
+        o.softmax_lsce(z, tgt.view(-1), loss, dz, prob, B, C, 0.1)
+        assert abs(float(loss) - float(ref)) < 1e-5
+        close(dz, zr.grad, 1e-4, 1e-6, "dlogits")
+        close(prob, torch.softmax(z, 1), 1e-5, 1e-6, "prob")
+
+
+# ---------------------------------------------------------------- tokens, misc, optim
+def test_tokens_and_misc(dev):
+    o = ops()
+    g = torch.Generator().manual_seed(9)
+    n_img, N, D = 6, 37, 384
+    cls = torch.randn(D, generator=g).to(dev); pos = torch.randn(N, D, generator=g).to(dev)
+    x = torch.zeros(n_img * N, D, device=dev)
+    o.cls_rows(x, cls, pos, n_img, N, D)
+    close(x.view(n_img, N, D)[:, 0], (cls + pos[0]).expand(n_img, D), 0, 1e-6, "cls rows")
+    gg = torch.randn(n_img * N, D, generator=g).to(dev)
+    gp = torch.empty(n_img * (N - 1), D, dtype=bf16, device=dev); dpos = torch.ones(N, D, device=dev); dcls = torch.ones(D, device=dev)
+    o.tokens_bwd(gg, gp, dpos, dcls, n_img, N, D, accumulate=True)
+    gv = gg.view(n_img, N, D)
+    close(dpos, 1 + gv.sum(0), 1e-5, 1e-5, "dpos"); close(dcls, 1 + gv[:, 0].sum(0), 1e-5, 1e-5, "dcls")
+    close(gp, gv[:, 1:].reshape(-1, D), 8e-3, 1e-3, "gpatch")
+    y = torch.empty(n_img, D, dtype=bf16, device=dev)
+    o.gather_cls(gg, y, n_img, N, D)
+    close(y, gv[:, 0], 8e-3, 1e-3, "gather cls")
+    A = torch.randn(36, 196, generator=g).to(dev); Bm = torch.randn(196, D, generator=g).to(dev)
+    C = torch.empty(36, D, device=dev)
+    o.small_matmul(A, Bm, C, 36, D, 196)
+    close(C, A @ Bm, 1e-4, 1e-4, "small matmul")
+    C2 = torch.ones(196, D, device=dev); Bt = torch.randn(36, D, generator=g).to(dev)
+    o.small_matmul(A, Bt, C2, 196, D, 36, trans_a=True, accumulate=True)
+    close(C2, 1 + A.t() @ Bt, 1e-4, 1e-4, "small matmul T")
+    n = 1_000_003
+    src = torch.randn(n, generator=g).to(dev); dst = torch.empty(n, dtype=bf16, device=dev)
+    o.cast_bf16(src, dst)
+    assert torch.equal(dst, src.to(bf16))
+    ws = torch.empty(1024, device=dev); out = torch.empty(1, device=dev)
+    o.sumsq(src, ws, out)
+    assert abs(float(out) - float((src.double() ** 2).sum())) < 1e-3 * n
+
+
+def test_adamw_ema(dev):
+    o = ops()
+    n = 4096 * 33
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(n, generator=g).to(dev); grad = torch.randn(n, generator=g).to(dev)
+    t0 = torch.randn(n, generator=g).to(dev)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.04)
+    p = p0.clone(); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    pb = torch.empty(n, dtype=bf16, device=dev); t = t0.clone(); tb = torch.empty(n, dtype=bf16, device=dev)
+    tref = t0.clone()
+    for step in (1, 2, 3):
+        pr.grad = grad.clone() * step
+        opt.step()
+        tref = 0.99 * tref + 0.01 * pr.detach()
+        o.adamw_ema(p, grad * step, m, v, pb, t, tb, n, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.04,
+                    step=step, teacher_momentum=0.99)
+    close(p, pr.detach(), 1e-5, 1e-6, "adamw p")
+    close(t, tref, 1e-5, 1e-6, "ema teacher")
+    assert torch.equal(pb, p.to(bf16)) and torch.equal(tb, t.to(bf16))
+    # clipping: scale = clip / (||g|| + 1e-6)
+    p2 = p0.clone(); m.zero_(); v.zero_()
+    gn = torch.tensor([float((grad.double() ** 2).sum())], device=dev)
+    o.adamw_ema(p2, grad, m, v, None, None, None, n, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step=1,
+                clip_norm=3.0, gnorm_sq=gn)
+    c = 3.0 / (math.sqrt(float(gn)) + 1e-6)
+    close(m, 0.1 * grad * c, 1e-4, 1e-7, "clipped m")
