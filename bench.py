@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""bench.py -- tiles/s of one full DINO multi-crop training step (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config c3|c2] [--no-graph]
+
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).  A step = teacher forward on
+the 2 global crops + student forward/backward on 2x224 + 8x96 crops of B synthetic 256-px
+NHWC uint8 tiles per GPU (resident in HBM before the timed region) + DINO loss + gradient /
+center all-reduce (RCCL) + AdamW + teacher EMA.  ViT-S/16, K = 65536, bf16 MFMA with f32
+accumulation / master weights.  Rank 0 prints ONE JSON line (contract in DESIGN.md).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_TILE = {"c3": 113.83, "c2": 73.93}
+MFMA_BF16_PEAK_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: dense bf16
+
+
+def synth_tiles(B, size, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.tensor((0.8998, 0.8253, 0.9357)) * 255.0
+    std = torch.tensor((0.1125, 0.1751, 0.0787)) * 255.0
+    x = torch.randn(B, size, size, 3, generator=g) * std + mean
+    return x.round().clamp(0, 255).to(torch.uint8).to(device)
+
+
+def cpu_baseline(arch, n_local, seconds_budget=25.0):
+    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded
+    sample of the same workload: B=2 tiles per step, K=65536, as many steps as fit."""
+    from oracle import step_oracle as so, vit_oracle as vo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 2
+    orc = so.DinoOracle(arch=arch, img_size=224, out_dim=65536, n_local=n_local)
+    tiles = vo.synth_tiles(B, 256, seed=1234)
+    orc.step(tiles)                                   # warm-up
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
+        orc.step(tiles); n += 1
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{n} oracle steps of B={B} tiles (2x224+{n_local}x96 crops, {arch}, K=65536) after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
+    ap.add_argument("--config", default="c3", choices=["c3", "c2"])
+    ap.add_argument("--arch", default="vit_small")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-timing", action="store_true", help="time the dominant GEMM with HIP events for the roofline object")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    reducer = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        from gipvit.dist import RcclReducer
+        reducer = RcclReducer()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from gipvit.engine import DinoEngine
+    from gipvit import roofline
+    n_local = 8 if args.config == "c3" else 0
+    eng = DinoEngine(arch=args.arch, img_size=224, out_dim=65536, batch=args.batch, n_local=n_local, device=dev, reducer=reducer)
+    from gipvit.models import init_vit_state, init_dino_head_state
+    eng.load_state(init_vit_state(args.arch, 224, 0, seed=0), init_dino_head_state(eng.D, 65536, seed=1))
+    tiles = synth_tiles(args.batch, 256, 1234 + rank, dev)
+
+    use_graph = not args.no_graph
+    if use_graph:
+        eng.capture(tiles)
+    step = (lambda: eng.step_graph()) if use_graph else (lambda: eng.step(tiles))
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(eng.loss)
+
+    if rank == 0:
+        tiles_s = args.batch * world * args.steps / dt
+        out = {
+            "metric": "tiles/sec/GPU ViT-S/16 DINO (2g+8l crops, 256px) at 1/2/4/8 MI355X",
+            "value": round(tiles_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.arch}/16 DINO 2x224+{n_local}x96 crops of 256px NHWC u8 tiles, K=65536 ({args.config})",
+                       "tiles_per_gpu": args.batch, "global_tiles": args.batch * world, "parallelism": f"dp{world}",
+                       "hipgraph": use_graph},
+            "tiles_per_s_per_gpu": round(tiles_s / world, 2),
+            "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[args.config] / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
+            if args.arch == "vit_small" else None,
+            "final_loss": round(loss, 4),
+        }
+        out["roofline"] = roofline.dominant_kernel_roofline(eng, args.batch) if world == 1 else None
+        out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch, n_local)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,7 +46,8 @@ gv_cls_rows_args = _struct("gv_cls_rows_args", [("x", vp), ("cls", vp), ("pos", 
 gv_tokens_bwd_args = _struct("gv_tokens_bwd_args", [
     ("g", vp), ("gpatch", vp), ("dpos", vp), ("dcls", vp), ("n_img", i32), ("N", i32), ("D", i32), ("accumulate", i32)])
 gv_small_matmul_args = _struct("gv_small_matmul_args", [
-    ("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("trans_a", i32), ("accumulate", i32)])
+    ("A", vp), ("a_is_bf16", i32), ("sam", i64), ("sak", i64), ("B", vp), ("b_is_bf16", i32), ("sbk", i64), ("sbn", i64),
+    ("C", vp), ("c_is_bf16", i32), ("ldc", i64), ("bias", vp), ("M", i32), ("N", i32), ("K", i32), ("accumulate", i32)])
 gv_l2norm_fwd_args = _struct("gv_l2norm_fwd_args", [("x", vp), ("y", vp), ("inv_norm", vp), ("rows", i32), ("C", i32)])
 gv_l2norm_bwd_args = _struct("gv_l2norm_bwd_args", [("dy", vp), ("y", vp), ("inv_norm", vp), ("dx", vp), ("rows", i32), ("C", i32)])
 gv_weightnorm_fwd_args = _struct("gv_weightnorm_fwd_args", [("v", vp), ("g", vp), ("w", vp), ("rows", i32), ("C", i32)])
@@ -54,7 +55,7 @@ gv_weightnorm_bwd_args = _struct("gv_weightnorm_bwd_args", [
     ("dw", vp), ("v", vp), ("g", vp), ("dv", vp), ("dg", vp), ("rows", i32), ("C", i32), ("accumulate", i32)])
 gv_dino_loss_args = _struct("gv_dino_loss_args", [
     ("student", vp), ("teacher", vp), ("center", vp), ("dstudent", vp), ("loss", vp), ("center_sum", vp), ("workspace", vp),
-    ("B", i32), ("V", i32), ("G", i32), ("K", i32), ("student_temp", f32), ("teacher_temp", f32), ("grad_scale", f32)])
+    ("B", i32), ("V", i32), ("G", i32), ("K", i32), ("student_temp", f32), ("teacher_temp", f32), ("grad_scale", f32), ("hyper", vp)])
 gv_center_update_args = _struct("gv_center_update_args", [
     ("center", vp), ("center_sum", vp), ("K", i32), ("momentum", f32), ("inv_rows", f32)])
 gv_softmax_lsce_args = _struct("gv_softmax_lsce_args", [
@@ -65,7 +66,7 @@ gv_sumsq_args = _struct("gv_sumsq_args", [("x", vp), ("n", i64), ("workspace", v
 gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
     ("p", vp), ("grad", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("teacher", vp), ("teacher_bf16", vp), ("n", i64),
     ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bias_corr1", f32), ("bias_corr2", f32),
-    ("grad_scale", f32), ("clip_norm", f32), ("gnorm_sq", vp), ("teacher_momentum", f32)])
+    ("grad_scale", f32), ("clip_norm", f32), ("gnorm_sq", vp), ("teacher_momentum", f32), ("hyper", vp)])
 
 # entry point -> argument struct (every `int gv_*(const args*, void* stream)` of the header)
 ENTRY_POINTS = {
@@ -82,6 +83,7 @@ PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target")
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_POS, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 LN_PARTIAL_BLOCKS = 512
+HYP_LR, HYP_WD, HYP_BC1, HYP_BC2, HYP_TEACHER_MOM, HYP_GRAD_SCALE, HYP_TEACHER_TEMP, HYP_STUDENT_TEMP, HYP_COUNT = range(9)
 
 
 class GipvitError(RuntimeError):

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(gv_dino_loss_args a) {
     const int row = blockIdx.x;
     const int ns = a.V * a.B;
     const bool teacher = row >= ns;
+    if (a.hyper) { a.teacher_temp = a.hyper[GV_HYP_TEACHER_TEMP]; a.student_temp = a.hyper[GV_HYP_STUDENT_TEMP]; }
     const float* x = teacher ? a.teacher + (long)(row - ns) * a.K : a.student + (long)row * a.K;
     const float inv_t = 1.0f / (teacher ? a.teacher_temp : a.student_temp);
     float m = -INFINITY, s = 0.f;
@@ -48,6 +49,10 @@ __global__ __launch_bounds__(256) void row_stats_kernel(gv_dino_loss_args a) {
 // grid (K/256, bsplit); thread = one class k, loops over its slice of the batch
 __global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int b_per, float coef, float inv_pairs_b) {
     __shared__ float red[4];
+    if (a.hyper) {   // coef was built with the by-value student temperature
+        coef *= a.student_temp / a.hyper[GV_HYP_STUDENT_TEMP];
+        a.teacher_temp = a.hyper[GV_HYP_TEACHER_TEMP]; a.student_temp = a.hyper[GV_HYP_STUDENT_TEMP];
+    }
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int b0 = blockIdx.y * b_per, b1 = min(a.B, b0 + b_per);
     const int V = a.V, G = a.G, B = a.B, K = a.K;

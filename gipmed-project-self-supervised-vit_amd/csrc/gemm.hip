@@ -289,26 +289,32 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     p.ksplit = 1; p.k_per_split = ((a->K + BK - 1) / BK) * BK;
     hipStream_t s = (hipStream_t)stream;
 
-    if (ta && tb) {
-        // dW: reduction over tokens.  Split K when the output grid alone cannot fill
-        // 256 CUs; partial sums meet in C through f32 atomics, which needs ACCUM
-        // semantics (C already holds the value to add to).
+    // Split K when the output grid alone cannot fill 256 CUs (dW: reduction over tens of
+    // thousands of tokens; the 65536-class DINO head's dX).  Partial sums meet in C through
+    // f32 atomics, which needs pure ACCUM semantics (C already holds the value to add to).
+    {
         const int tiles = p.tiles_m * p.tiles_n;
-        const bool only_accum = a->c_is_f32 && (e & ~GV_EPI_ACCUM) == 0 && (e & GV_EPI_ACCUM);
+        const bool only_accum = a->c_is_f32 && e == GV_EPI_ACCUM;
         if (only_accum && tiles < 384) {
-            int want = (512 + tiles - 1) / tiles;
-            int ksteps = (a->K + BK - 1) / BK;
-            int maxs = ksteps / 8 > 0 ? ksteps / 8 : 1;   // at least 8 k-steps (512 rows) per slice
-            int S = want < maxs ? want : maxs;
+            const int want = (512 + tiles - 1) / tiles;
+            const int ksteps = (a->K + BK - 1) / BK;
+            const int maxs = ksteps / 8 > 0 ? ksteps / 8 : 1;   // at least 8 k-steps (512 deep) per slice
+            const int S = want < maxs ? want : maxs;
             if (S > 1) {
-                int per = (ksteps + S - 1) / S;
+                const int per = (ksteps + S - 1) / S;
                 p.k_per_split = per * BK;
                 p.ksplit = (ksteps + per - 1) / per;
             }
         }
+    }
+    if (ta && tb) {
         if (p.ksplit > 1) return launch<true, true, float, true>(p, s);
         return a->c_is_f32 ? launch<true, true, float, false>(p, s) : launch<true, true, bf16, false>(p, s);
     }
-    if (!ta && tb) return a->c_is_f32 ? launch<false, true, float, false>(p, s) : launch<false, true, bf16, false>(p, s);
+    if (!ta && tb) {
+        if (p.ksplit > 1) return launch<false, true, float, true>(p, s);
+        return a->c_is_f32 ? launch<false, true, float, false>(p, s) : launch<false, true, bf16, false>(p, s);
+    }
+    if (p.ksplit > 1) return launch<false, false, float, true>(p, s);
     return a->c_is_f32 ? launch<false, false, float, false>(p, s) : launch<false, false, bf16, false>(p, s);
 }

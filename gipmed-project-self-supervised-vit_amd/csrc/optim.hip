@@ -8,6 +8,11 @@
 namespace {
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
+    if (a.hyper) {
+        a.lr = a.hyper[GV_HYP_LR]; a.weight_decay *= a.hyper[GV_HYP_WD];   // by-value wd is a 0/1 multiplier here
+        a.bias_corr1 = a.hyper[GV_HYP_BC1]; a.bias_corr2 = a.hyper[GV_HYP_BC2];
+        a.teacher_momentum = a.hyper[GV_HYP_TEACHER_MOM]; a.grad_scale = a.hyper[GV_HYP_GRAD_SCALE];
+    }
     float gscale = a.grad_scale;
     if (a.clip_norm > 0.f) {
         const float nrm = sqrtf(*a.gnorm_sq) * fabsf(a.grad_scale);
@@ -45,7 +50,7 @@ extern "C" int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream) {
     GV_REQUIRE(gv_aligned(a->p, 16) && gv_aligned(a->grad, 16) && gv_aligned(a->m, 16) && gv_aligned(a->v, 16), GV_E_ALIGN,
                "gv_adamw_ema: buffers must be 16-byte aligned");
     if (a->clip_norm > 0.f) GV_REQUIRE(a->gnorm_sq, GV_E_NULL, "gv_adamw_ema: clip_norm needs gnorm_sq");
-    GV_REQUIRE(a->bias_corr1 > 0.f && a->bias_corr2 > 0.f, GV_E_SHAPE, "gv_adamw_ema: bias corrections must be > 0");
+    if (!a->hyper) GV_REQUIRE(a->bias_corr1 > 0.f && a->bias_corr2 > 0.f, GV_E_SHAPE, "gv_adamw_ema: bias corrections must be > 0");
     long blocks = (a->n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
     GV_LAUNCH_CHECK("gv_adamw_ema");

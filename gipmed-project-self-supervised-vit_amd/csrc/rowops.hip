@@ -36,11 +36,20 @@ __global__ void small_matmul_kernel(gv_small_matmul_args a) {
     if (n >= a.N) return;
     float s = 0.f;
     for (int k = 0; k < a.K; ++k) {
-        const float av = a.trans_a ? a.A[(long)k * a.M + m] : a.A[(long)m * a.K + k];
-        s += av * a.B[(long)k * a.N + n];
+        const long ia = m * a.sam + k * a.sak, ib = k * a.sbk + n * a.sbn;
+        const float av = a.a_is_bf16 ? (float)((const bf16*)a.A)[ia] : ((const float*)a.A)[ia];
+        const float bv = a.b_is_bf16 ? (float)((const bf16*)a.B)[ib] : ((const float*)a.B)[ib];
+        s += av * bv;
     }
-    float* c = a.C + (long)m * a.N + n;
-    *c = a.accumulate ? *c + s : s;
+    if (a.bias) s += a.bias[n];
+    const long ic = (long)m * a.ldc + n;
+    if (a.c_is_bf16) {
+        bf16* c = (bf16*)a.C + ic;
+        *c = (bf16)(a.accumulate ? (float)*c + s : s);
+    } else {
+        float* c = (float*)a.C + ic;
+        *c = a.accumulate ? *c + s : s;
+    }
 }
 
 // one wave per row, C = 256 (DINOHead bottleneck): 4 columns per lane

@@ -1,0 +1,606 @@
+"""Host-side sequencing of the hot path over the C ABI (no autograd, no torch math).
+
+Mirrors, for this path only, what the reference reaches through timm's
+``VisionTransformer`` + ``loss.backward()`` + ``optimizer.step()``
+(reference train.py:1044-1078) and what the orphaned DINO ViT / DINOHead
+bytecode specifies (``vit.pyc@L..``):
+
+  * ``Arena``     -- every parameter of (backbone [+ head]) in ONE flat f32 buffer with
+                     matching flat gradient / Adam-moment / bf16 / teacher buffers, so the
+                     optimizer + EMA + bf16 refresh is one fused pass and the data-parallel
+                     reduction is a few large RCCL calls over contiguous ranges.  Weight-decayed
+                     matrices come first, in the order their gradients complete in backward.
+  * ``VitGroup``  -- activations of one crop-resolution group (multi-crop wrapper, row D1).
+  * ``VitRunner`` -- forward / backward of the encoder as explicit launch sequences.
+  * ``DinoEngine`` / ``SupervisedEngine`` -- one training step (rows S1, D1-D5, L1, O1).
+
+Everything is launched on the current stream with static buffers, so a whole step
+can be captured in a hipGraph (``capture=True``).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+ARCHS = {   # vit.pyc@L275-293
+    "vit_tiny": dict(embed_dim=192, depth=12, num_heads=3),
+    "vit_small": dict(embed_dim=384, depth=12, num_heads=6),
+    "vit_base": dict(embed_dim=768, depth=12, num_heads=12),
+}
+MEAN_RON = (0.8998, 0.8253, 0.9357)   # transformations.py:106
+STD_RON = (0.1125, 0.1751, 0.0787)    # transformations.py:113
+PAD = 64                              # arena offsets are multiples of 64 elements
+
+
+def _round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------- #
+# parameter inventory (timm / DINO state_dict names)
+# --------------------------------------------------------------------------- #
+def vit_param_specs(arch: str, img_size: int, num_classes: int = 0) -> "OrderedDict[str, Tuple[int, ...]]":
+    a = ARCHS[arch]
+    D, depth = a["embed_dim"], a["depth"]
+    P = (img_size // 16) ** 2
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["cls_token"] = (1, 1, D)
+    s["pos_embed"] = (1, P + 1, D)
+    s["patch_embed.proj.weight"] = (D, 3, 16, 16)
+    s["patch_embed.proj.bias"] = (D,)
+    for i in range(depth):
+        b = f"blocks.{i}."
+        s[b + "norm1.weight"] = (D,); s[b + "norm1.bias"] = (D,)
+        s[b + "attn.qkv.weight"] = (3 * D, D); s[b + "attn.qkv.bias"] = (3 * D,)
+        s[b + "attn.proj.weight"] = (D, D); s[b + "attn.proj.bias"] = (D,)
+        s[b + "norm2.weight"] = (D,); s[b + "norm2.bias"] = (D,)
+        s[b + "mlp.fc1.weight"] = (4 * D, D); s[b + "mlp.fc1.bias"] = (4 * D,)
+        s[b + "mlp.fc2.weight"] = (D, 4 * D); s[b + "mlp.fc2.bias"] = (D,)
+    s["norm.weight"] = (D,); s["norm.bias"] = (D,)
+    if num_classes > 0:
+        s["head.weight"] = (num_classes, D); s["head.bias"] = (num_classes,)
+    return s
+
+
+def dino_head_specs(in_dim: int, out_dim: int, hidden: int = 2048, bottleneck: int = 256):
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()   # vit.pyc@L296-318
+    s["mlp.0.weight"] = (hidden, in_dim); s["mlp.0.bias"] = (hidden,)
+    s["mlp.2.weight"] = (hidden, hidden); s["mlp.2.bias"] = (hidden,)
+    s["mlp.4.weight"] = (bottleneck, hidden); s["mlp.4.bias"] = (bottleneck,)
+    s["last_layer.weight_g"] = (out_dim, 1)
+    s["last_layer.weight_v"] = (out_dim, bottleneck)
+    return s
+
+
+def no_weight_decay(name: str, shape) -> bool:
+    """timm create_optimizer_v2 filter: 1-D, *.bias, pos_embed, cls_token."""
+    base = name.split(".", 1)[1] if name.startswith(("backbone.", "head.")) else name
+    return len(shape) <= 1 or name.endswith(".bias") or base in ("pos_embed", "cls_token") or name.endswith("weight_g")
+
+
+class Arena:
+    """Flat parameter storage.  ``order`` lists names in arena order."""
+
+    def __init__(self, specs: "OrderedDict[str, Tuple[int, ...]]", device, teacher: bool):
+        decay = [n for n, s in specs.items() if not no_weight_decay(n, s)]
+        nodecay = [n for n, s in specs.items() if no_weight_decay(n, s)]
+        decay.reverse()                      # gradients complete head-first, block 11 .. 0, patch embed last
+        self.specs, self.order = specs, decay + nodecay
+        self.off: Dict[str, int] = {}
+        o = 0
+        for n in decay:
+            self.off[n] = o
+            o += _round_up(math.prod(specs[n]), PAD)
+        self.n_decay = o
+        for n in nodecay:
+            self.off[n] = o
+            o += _round_up(math.prod(specs[n]), PAD)
+        self.n = o
+        z = lambda dt: torch.zeros(self.n, dtype=dt, device=device)
+        self.p, self.g, self.m, self.v, self.pb = z(f32), z(f32), z(f32), z(f32), z(bf16)
+        self.t, self.tb = (z(f32), z(bf16)) if teacher else (None, None)
+
+    def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        shape = self.specs[name]
+        o = self.off[name]
+        return buf[o:o + math.prod(shape)].view(shape)
+
+    def load(self, state: Dict[str, torch.Tensor]):
+        for n in self.specs:
+            self.view(self.p, n).copy_(state[n].to(f32))
+
+    def state_dict(self, buf=None, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
+        buf = self.p if buf is None else buf
+        return OrderedDict((n[len(prefix):], self.view(buf, n).detach().clone()) for n in self.specs if n.startswith(prefix))
+
+
+class Weights:
+    """Accessor over one weight set of an arena (student or teacher) with a name prefix."""
+
+    def __init__(self, arena: Arena, prefix: str, teacher: bool = False):
+        self.a, self.prefix, self.teacher = arena, prefix, teacher
+
+    def w(self, name):      # bf16 matrix used as a GEMM operand
+        return self.a.view(self.a.tb if self.teacher else self.a.pb, self.prefix + name)
+
+    def f(self, name):      # f32 parameter (bias, LN, pos, cls)
+        return self.a.view(self.a.t if self.teacher else self.a.p, self.prefix + name)
+
+    def g(self, name):      # f32 gradient
+        return self.a.view(self.a.g, self.prefix + name)
+
+
+# --------------------------------------------------------------------------- #
+# bicubic pos-embed resampling as a fixed linear map (vit.pyc@L213-233)
+# --------------------------------------------------------------------------- #
+def pos_interp_matrix(n_src_side: int, crop: int) -> torch.Tensor:
+    """[P_dst, P_src] matrix M with interpolate(pos) = M @ pos, built by pushing the
+    identity basis through the exact torch call the reference makes."""
+    import torch.nn.functional as F
+    Ns = n_src_side * n_src_side
+    w0 = crop // 16 + 0.1
+    eye = torch.eye(Ns, dtype=torch.float64).reshape(1, n_src_side, n_src_side, Ns).permute(0, 3, 1, 2)
+    out = F.interpolate(eye, scale_factor=(w0 / n_src_side, w0 / n_src_side), mode="bicubic")
+    side = crop // 16
+    assert out.shape[-1] == side and out.shape[-2] == side
+    return out.permute(0, 2, 3, 1).reshape(side * side, Ns).to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------- #
+# activations of one crop group
+# --------------------------------------------------------------------------- #
+class VitGroup:
+    def __init__(self, arch: str, n_img: int, crop: int, img_size: int, device, save: bool):
+        a = ARCHS[arch]
+        D, depth, H = a["embed_dim"], a["depth"], a["num_heads"]
+        self.n_img, self.crop, self.save = n_img, crop, save
+        self.P = (crop // 16) ** 2
+        self.N = self.P + 1
+        self.T = n_img * self.N
+        T, nb = self.T, (depth if save else 1)
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
+        self.patches = e((n_img * self.P, 768), bf16)
+        self.x = [e((T, D), f32) for _ in range(2 * depth + 1 if save else 3)]
+        self.xn1 = [e((T, D), bf16) for _ in range(nb)]
+        self.xn2 = [e((T, D), bf16) for _ in range(nb)]
+        self.qkv = [e((T, 3 * D), bf16) for _ in range(nb)]
+        self.o = [e((T, D), bf16) for _ in range(nb)]
+        self.lse = [e((n_img, H, self.N), f32) for _ in range(nb)]
+        self.hp = [e((T, 4 * D), bf16) for _ in range(nb)]
+        self.h = [e((T, 4 * D), bf16) for _ in range(nb)]
+        self.stats = [[e((T,), f32) for _ in range(4)] for _ in range(nb)]   # mean1, rstd1, mean2, rstd2
+        self.fstats = [e((n_img,), f32) for _ in range(2)]
+        self.pos = None if crop == img_size else e((self.N, D), f32)
+        self.interp = None if crop == img_size else pos_interp_matrix(img_size // 16, crop).to(device)
+        if save:   # backward scratch
+            self.g, self.gb = e((T, D), f32), e((T, D), bf16)
+            self.dh = e((T, 4 * D), bf16)
+            self.dxn = e((T, D), bf16)
+            self.dqkv = e((T, 3 * D), bf16)
+            self.do = e((T, D), bf16)
+            self.gpatch = e((n_img * self.P, D), bf16)
+            self.dpos = e((self.N, D), f32)
+
+    def xbuf(self, j):
+        return self.x[j] if self.save else self.x[j % 3]
+
+    def slot(self, i):
+        return i if self.save else 0
+
+
+class VitRunner:
+    def __init__(self, arch: str, img_size: int, device):
+        a = ARCHS[arch]
+        self.arch, self.D, self.depth, self.H, self.img_size = arch, a["embed_dim"], a["depth"], a["num_heads"], img_size
+        self.scale = 64 ** -0.5
+        self.partials = torch.empty(L.LN_PARTIAL_BLOCKS, 3, self.D, dtype=f32, device=device)
+        self.cs_ws = torch.empty(64 * 4 * self.D, dtype=f32, device=device)
+        self.one = torch.ones(1, dtype=f32, device=device)
+
+    # ---- forward: tiles -> CLS features written into feats[row_off : row_off + n_img]
+    def forward(self, W: Weights, G: VitGroup, tiles_u8, windows, mean, std, feats, row_off: int):
+        D, T, N, P, H = self.D, G.T, G.N, G.P, self.H
+        E = L
+        ops.patchify(tiles_u8, windows, G.crop, mean, std, out=G.patches)
+        pos_full = W.f("pos_embed").view(-1, D)
+        if G.pos is None:
+            pos = pos_full
+        else:   # interpolate_pos_encoding: row 0 = cls pos, rows 1.. = M @ pos[1:]
+            pos = G.pos
+            Ps = pos_full.shape[0] - 1
+            ops.small_matmul(self.one, pos_full, pos, 1, D, 1, sam=0, sak=0, sbk=0, sbn=1)
+            ops.small_matmul(G.interp, pos_full[1:], pos[1:], P, D, Ps, sam=Ps, sak=1, sbk=D, sbn=1)
+        x0 = G.xbuf(0)
+        ops.cls_rows(x0, W.f("cls_token").view(-1), pos, G.n_img, N, D)
+        ops.linear(G.patches, W.w("patch_embed.proj.weight").view(D, 768), x0, G.n_img * P, D, 768,
+                   epilogue=E.EPI_BIAS | E.EPI_POS, bias=W.f("patch_embed.proj.bias"), pos=pos, P=P)
+        for i in range(self.depth):
+            b, s = f"blocks.{i}.", G.slot(i)
+            xa, xb, xc = G.xbuf(2 * i), G.xbuf(2 * i + 1), G.xbuf(2 * i + 2)
+            st = G.stats[s]
+            ops.layernorm_fwd(xa, W.f(b + "norm1.weight"), W.f(b + "norm1.bias"), T, D, y=G.xn1[s], mean=st[0], rstd=st[1])
+            ops.linear(G.xn1[s], W.w(b + "attn.qkv.weight"), G.qkv[s], T, 3 * D, D, epilogue=E.EPI_BIAS, bias=W.f(b + "attn.qkv.bias"))
+            ops.attention_fwd(G.qkv[s], G.n_img, N, H, self.scale, o=G.o[s], lse=G.lse[s])
+            ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
+                       bias=W.f(b + "attn.proj.bias"), resid=xa)
+            ops.layernorm_fwd(xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), T, D, y=G.xn2[s], mean=st[2], rstd=st[3])
+            ops.linear(G.xn2[s], W.w(b + "mlp.fc1.weight"), G.h[s], T, 4 * D, D, epilogue=E.EPI_BIAS | E.EPI_GELU | E.EPI_SAVE_PRE,
+                       bias=W.f(b + "mlp.fc1.bias"), aux_out=G.hp[s])
+            ops.linear(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
+                       bias=W.f(b + "mlp.fc2.bias"), resid=xb)
+        xl = G.xbuf(2 * self.depth)
+        ops.layernorm_fwd(xl, W.f("norm.weight"), W.f("norm.bias"), G.n_img, D, x_stride=N * D,
+                          y=feats[row_off:row_off + G.n_img], mean=G.fstats[0], rstd=G.fstats[1])
+
+    def _fin(self, which: int, out: torch.Tensor):
+        ops.colsum_finalize(self.partials, L.LN_PARTIAL_BLOCKS, 3, which, self.D, out, True)
+
+    # ---- backward from d(CLS features) bf16 [n_img, D]; gradients ACCUMULATE into the arena
+    def backward(self, W: Weights, G: VitGroup, dfeat: torch.Tensor):
+        D, T, N, P, H = self.D, G.T, G.N, G.P, self.H
+        E = L
+        ACC = E.EPI_ACCUM
+        G.g.zero_(); G.gb.zero_()
+        xl = G.x[2 * self.depth]
+        ops.layernorm_bwd(dfeat, xl, G.fstats[0], G.fstats[1], W.f("norm.weight"), G.g, G.gb, self.partials, G.n_img, D,
+                          x_stride=N * D, g_stride=N * D, gb_stride=N * D, g_init=True)
+        self._fin(0, W.g("norm.weight")); self._fin(1, W.g("norm.bias"))
+        self._fin(2, W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
+        for i in reversed(range(self.depth)):
+            b, st = f"blocks.{i}.", G.stats[i]
+            # MLP
+            ops.linear(G.gb, W.w(b + "mlp.fc2.weight"), G.dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
+            ops.linear(G.gb, G.h[i], W.g(b + "mlp.fc2.weight"), D, 4 * D, T, trans_a=True, trans_b=True, epilogue=ACC)
+            ops.linear(G.dh, W.w(b + "mlp.fc1.weight"), G.dxn, T, D, 4 * D, trans_b=True)
+            ops.linear(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
+            ops.colsum(G.dh, T, 4 * D, self.cs_ws, W.g(b + "mlp.fc1.bias"), accumulate=True)
+            ops.layernorm_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), G.g, G.gb, self.partials, T, D)
+            self._fin(0, W.g(b + "norm2.weight")); self._fin(1, W.g(b + "norm2.bias")); self._fin(2, W.g(b + "attn.proj.bias"))
+            # attention
+            ops.linear(G.gb, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
+            ops.linear(G.gb, G.o[i], W.g(b + "attn.proj.weight"), D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
+            ops.attention_bwd(G.qkv[i], G.o[i], G.do, G.lse[i], G.n_img, N, H, self.scale, dqkv=G.dqkv)
+            ops.linear(G.dqkv, W.w(b + "attn.qkv.weight"), G.dxn, T, D, 3 * D, trans_b=True)
+            ops.linear(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
+            ops.colsum(G.dqkv, T, 3 * D, self.cs_ws, W.g(b + "attn.qkv.bias"), accumulate=True)
+            ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, G.gb, self.partials, T, D)
+            self._fin(0, W.g(b + "norm1.weight")); self._fin(1, W.g(b + "norm1.bias"))
+            if i > 0:
+                self._fin(2, W.g(f"blocks.{i - 1}.mlp.fc2.bias"))
+        # token assembly + patch embedding
+        ops.tokens_bwd(G.g, G.gpatch, G.dpos, None, G.n_img, N, D, accumulate=False)
+        # d cls_token = sum over images of the CLS-row gradient = dpos row 0
+        ops.small_matmul(self.one, G.dpos, W.g("cls_token").view(1, D), 1, D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
+        ops.linear(G.gpatch, G.patches, W.g("patch_embed.proj.weight").view(D, 768), D, 768, G.n_img * P,
+                   trans_a=True, trans_b=True, epilogue=ACC)
+        ops.colsum(G.dpos[1:], P, D, self.cs_ws, W.g("patch_embed.proj.bias"), accumulate=True)
+        gpos = W.g("pos_embed").view(-1, D)
+        if G.pos is None:
+            ops.small_matmul(self.one, G.dpos, gpos, 1, N * D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
+        else:
+            Ps = gpos.shape[0] - 1
+            ops.small_matmul(self.one, G.dpos, gpos, 1, D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
+            ops.small_matmul(G.interp, G.dpos[1:], gpos[1:], Ps, D, P, sam=1, sak=Ps, sbk=D, sbn=1, accumulate=True)
+
+
+# --------------------------------------------------------------------------- #
+# DINO head (vit.pyc@L296-330) forward / backward over R rows
+# --------------------------------------------------------------------------- #
+class HeadBuffers:
+    def __init__(self, R: int, D: int, K: int, hidden: int, bott: int, device, save: bool):
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
+        self.R = R
+        self.feats = e((R, D), bf16)
+        self.h1p, self.h1 = e((R, hidden), bf16), e((R, hidden), bf16)
+        self.h2p, self.h2 = e((R, hidden), bf16), e((R, hidden), bf16)
+        self.z, self.zn, self.inv = e((R, bott), f32), e((R, bott), bf16), e((R,), f32)
+        self.logits = e((R, K), f32)
+        if save:
+            self.dlogits = e((R, K), bf16)
+            self.dzn, self.dz = e((R, bott), f32), e((R, bott), bf16)
+            self.dh2, self.dh1 = e((R, hidden), bf16), e((R, hidden), bf16)
+            self.dfeats = e((R, D), bf16)
+            self.dwn = e((K, bott), f32)
+
+
+class HeadRunner:
+    def __init__(self, D: int, K: int, hidden: int, bott: int, device):
+        self.D, self.K, self.hidden, self.bott = D, K, hidden, bott
+        self.cs_ws = torch.empty(64 * max(hidden, bott), dtype=f32, device=device)
+
+    def forward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers):
+        R, D, Hd, Bt, K, E = hb.R, self.D, self.hidden, self.bott, self.K, L
+        ops.linear(hb.feats, W.w("mlp.0.weight"), hb.h1, R, Hd, D, epilogue=E.EPI_BIAS | E.EPI_GELU | E.EPI_SAVE_PRE,
+                   bias=W.f("mlp.0.bias"), aux_out=hb.h1p)
+        ops.linear(hb.h1, W.w("mlp.2.weight"), hb.h2, R, Hd, Hd, epilogue=E.EPI_BIAS | E.EPI_GELU | E.EPI_SAVE_PRE,
+                   bias=W.f("mlp.2.bias"), aux_out=hb.h2p)
+        ops.linear(hb.h2, W.w("mlp.4.weight"), hb.z, R, Bt, Hd, epilogue=E.EPI_BIAS, bias=W.f("mlp.4.bias"))
+        ops.l2norm_fwd(hb.z, hb.zn, hb.inv, R, Bt)
+        ops.linear(hb.zn, wn, hb.logits, R, K, Bt)
+
+    def backward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers, train_last_layer: bool = True):
+        R, D, Hd, Bt, K, E = hb.R, self.D, self.hidden, self.bott, self.K, L
+        ACC = E.EPI_ACCUM
+        if train_last_layer:   # dW_n = dlogits^T zn, then through weight_norm (g frozen: norm_last_layer)
+            ops.linear(hb.dlogits, hb.zn, hb.dwn, K, Bt, R, trans_a=True, trans_b=True)
+            ops.weightnorm_bwd(hb.dwn, W.f("last_layer.weight_v"), W.f("last_layer.weight_g").view(-1),
+                               W.g("last_layer.weight_v"), None, K, Bt, accumulate=True)
+        hb.dzn.zero_()         # split-K over the K=65536 classes accumulates with atomics
+        ops.linear(hb.dlogits, wn, hb.dzn, R, Bt, K, trans_b=True, epilogue=ACC)
+        ops.l2norm_bwd(hb.dzn, hb.zn, hb.inv, hb.dz, R, Bt)
+        ops.linear(hb.dz, hb.h2, W.g("mlp.4.weight"), Bt, Hd, R, trans_a=True, trans_b=True, epilogue=ACC)
+        ops.colsum(hb.dz, R, Bt, self.cs_ws, W.g("mlp.4.bias"), accumulate=True)
+        ops.linear(hb.dz, W.w("mlp.4.weight"), hb.dh2, R, Hd, Bt, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h2p)
+        ops.linear(hb.dh2, hb.h1, W.g("mlp.2.weight"), Hd, Hd, R, trans_a=True, trans_b=True, epilogue=ACC)
+        ops.colsum(hb.dh2, R, Hd, self.cs_ws, W.g("mlp.2.bias"), accumulate=True)
+        ops.linear(hb.dh2, W.w("mlp.2.weight"), hb.dh1, R, Hd, Hd, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h1p)
+        ops.linear(hb.dh1, hb.feats, W.g("mlp.0.weight"), Hd, D, R, trans_a=True, trans_b=True, epilogue=ACC)
+        ops.colsum(hb.dh1, R, Hd, self.cs_ws, W.g("mlp.0.bias"), accumulate=True)
+        ops.linear(hb.dh1, W.w("mlp.0.weight"), hb.dfeats, R, D, Hd, trans_b=True)
+
+
+# --------------------------------------------------------------------------- #
+# data-parallel reduction hooks (engine stays importable without torch.distributed)
+# --------------------------------------------------------------------------- #
+class NoReducer:
+    world = 1
+
+    def reduce_range(self, buf, lo, hi):
+        pass
+
+    def reduce_tensor(self, t):
+        pass
+
+    def finish(self):
+        pass
+
+
+# --------------------------------------------------------------------------- #
+# one DINO multi-crop training step (paper Alg. 1)
+# --------------------------------------------------------------------------- #
+class DinoEngine:
+    def __init__(self, arch="vit_small", img_size=224, out_dim=65536, batch=64, tile=256, n_global=2, n_local=8,
+                 gsize=224, lsize=96, hidden=2048, bottleneck=256, lr=5e-4, weight_decay=0.04, betas=(0.9, 0.999), eps=1e-8,
+                 momentum_teacher=0.996, student_temp=0.1, teacher_temp=0.04, center_momentum=0.9, clip_grad: float = 0.0,
+                 mean=MEAN_RON, std=STD_RON, windows=None, device="cuda:0", reducer=None):
+        dev = torch.device(device)
+        self.dev, self.arch, self.B, self.tile = dev, arch, batch, tile
+        D = ARCHS[arch]["embed_dim"]
+        self.D, self.K, self.G, self.V = D, out_dim, n_global, n_global + n_local
+        self.mean, self.std = tuple(mean), tuple(std)
+        if windows is None:   # deterministic crop windows of SURVEY 8(d): (y0, x0)
+            windows = [(16 * g, 16 * g) for g in range(n_global)] + [(20 * l, 160 - 20 * l) for l in range(n_local)]
+        self.gwins, self.lwins = list(windows[:n_global]), list(windows[n_global:])
+        specs = OrderedDict(("backbone." + k, v) for k, v in vit_param_specs(arch, img_size, 0).items())
+        specs.update(("head." + k, v) for k, v in dino_head_specs(D, out_dim, hidden, bottleneck).items())
+        self.arena = Arena(specs, dev, teacher=True)
+        self.sW, self.tW = Weights(self.arena, "backbone."), Weights(self.arena, "backbone.", teacher=True)
+        self.sH, self.tH = Weights(self.arena, "head."), Weights(self.arena, "head.", teacher=True)
+        self.vit = VitRunner(arch, img_size, dev)
+        self.head = HeadRunner(D, out_dim, hidden, bottleneck, dev)
+        B = batch
+        self.g_glob = VitGroup(arch, n_global * B, gsize, img_size, dev, save=True)
+        self.g_loc = VitGroup(arch, n_local * B, lsize, img_size, dev, save=True) if n_local else None
+        self.g_teach = VitGroup(arch, n_global * B, gsize, img_size, dev, save=False)
+        self.hb_s = HeadBuffers(self.V * B, D, out_dim, hidden, bottleneck, dev, save=True)
+        self.hb_t = HeadBuffers(n_global * B, D, out_dim, hidden, bottleneck, dev, save=False)
+        self.wn_s = torch.empty(out_dim, bottleneck, dtype=bf16, device=dev)
+        self.wn_t = torch.empty(out_dim, bottleneck, dtype=bf16, device=dev)
+        self.center = torch.zeros(out_dim, dtype=f32, device=dev)
+        self.center_sum = torch.zeros(out_dim, dtype=f32, device=dev)
+        self.loss = torch.zeros(1, dtype=f32, device=dev)
+        self.loss_ws = torch.empty(2 * (self.V + self.G) * B, dtype=f32, device=dev)
+        self.gnorm_sq = torch.zeros(1, dtype=f32, device=dev)
+        self.red_ws = torch.empty(1024, dtype=f32, device=dev)
+        self.hyper = torch.zeros(L.HYP_COUNT, dtype=f32, device=dev)
+        self.hyper_host = torch.zeros(L.HYP_COUNT, dtype=f32).pin_memory() if torch.cuda.is_available() else torch.zeros(L.HYP_COUNT)
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.m_teacher, self.ts, self.tt, self.cm, self.clip = momentum_teacher, student_temp, teacher_temp, center_momentum, clip_grad
+        self.train_last_layer = True
+        self.t = 0
+        self.reducer = reducer if reducer is not None else NoReducer()
+        self.graph = None
+        self._static_tiles = None
+
+    # ---- parameters ----------------------------------------------------------------
+    def load_state(self, backbone: Dict[str, torch.Tensor], head: Dict[str, torch.Tensor]):
+        st = {"backbone." + k: v for k, v in backbone.items()}
+        st.update({"head." + k: v for k, v in head.items()})
+        self.arena.load(st)
+        self.arena.t.copy_(self.arena.p)            # teacher starts as a copy of the student
+        self.refresh_bf16()
+
+    def refresh_bf16(self):
+        a = self.arena
+        ops.cast_bf16(a.p, a.pb); ops.cast_bf16(a.t, a.tb)
+        self._refresh_wn()
+
+    def _refresh_wn(self):
+        bt = self.head.bott
+        ops.weightnorm_fwd(self.sH.f("last_layer.weight_v"), self.sH.f("last_layer.weight_g").view(-1), self.wn_s, self.K, bt)
+        ops.weightnorm_fwd(self.tH.f("last_layer.weight_v"), self.tH.f("last_layer.weight_g").view(-1), self.wn_t, self.K, bt)
+
+    def backbone_state_dict(self, teacher: bool = False):
+        return self.arena.state_dict(self.arena.t if teacher else self.arena.p, "backbone.")
+
+    def head_state_dict(self, teacher: bool = False):
+        return self.arena.state_dict(self.arena.t if teacher else self.arena.p, "head.")
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
+
+    # ---- the step --------------------------------------------------------------------
+    def set_hyper(self, lr=None, wd=None, momentum_teacher=None, teacher_temp=None):
+        """Stage the per-step schedule values into the device hyper vector (H2D on the
+        current stream, outside any captured graph)."""
+        self.t += 1
+        h = self.hyper_host
+        h[L.HYP_LR] = self.lr if lr is None else lr
+        h[L.HYP_WD] = self.wd if wd is None else wd
+        h[L.HYP_BC1] = 1.0 - self.betas[0] ** self.t
+        h[L.HYP_BC2] = 1.0 - self.betas[1] ** self.t
+        h[L.HYP_TEACHER_MOM] = self.m_teacher if momentum_teacher is None else momentum_teacher
+        h[L.HYP_GRAD_SCALE] = 1.0 / self.reducer.world
+        h[L.HYP_TEACHER_TEMP] = self.tt if teacher_temp is None else teacher_temp
+        h[L.HYP_STUDENT_TEMP] = self.ts
+        self.hyper.copy_(h, non_blocking=True)
+
+    def forward_backward(self, tiles_u8: torch.Tensor):
+        """teacher fwd (global crops) -> student fwd (all crops) -> loss -> backward.
+        Leaves un-reduced gradients in arena.g, loss in self.loss, center_sum."""
+        B, G, V = self.B, self.G, self.V
+        a = self.arena
+        a.g.zero_()
+        self.vit.forward(self.tW, self.g_teach, tiles_u8, self.gwins, self.mean, self.std, self.hb_t.feats, 0)
+        self.head.forward(self.tH, self.wn_t, self.hb_t)
+        self.vit.forward(self.sW, self.g_glob, tiles_u8, self.gwins, self.mean, self.std, self.hb_s.feats, 0)
+        if self.g_loc is not None:
+            self.vit.forward(self.sW, self.g_loc, tiles_u8, self.lwins, self.mean, self.std, self.hb_s.feats, G * B)
+        self.head.forward(self.sH, self.wn_s, self.hb_s)
+        ops.dino_loss(self.hb_s.logits, self.hb_t.logits, self.center, self.hb_s.dlogits, self.loss, self.center_sum,
+                      self.loss_ws, B, V, G, self.K, self.ts, self.tt, hyper=self.hyper)
+        self.reducer.reduce_tensor(self.center_sum)
+        self.head.backward(self.sH, self.wn_s, self.hb_s, self.train_last_layer)
+        # head gradients are final: start their reduction while the backbone runs backward
+        head_names = [n for n in a.order if n.startswith("head.") and a.off[n] < a.n_decay]
+        if head_names:
+            lo = min(a.off[n] for n in head_names)
+            hi = max(a.off[n] + _round_up(math.prod(a.specs[n]), PAD) for n in head_names)
+            self.reducer.reduce_range(a.g, lo, hi)
+            self._reduced_hi = hi
+        else:
+            self._reduced_hi = 0
+        if self.g_loc is not None:
+            self.vit.backward(self.sW, self.g_loc, self.hb_s.dfeats[G * B:])
+        self.vit.backward(self.sW, self.g_glob, self.hb_s.dfeats[:G * B])
+        self.reducer.reduce_range(a.g, self._reduced_hi, a.n)
+        self.reducer.finish()
+
+    def optimizer_step(self):
+        a = self.arena
+        if self.clip > 0:
+            ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
+        kw = dict(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=max(self.t, 1),
+                  clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None, hyper=self.hyper)
+        sl = slice(0, a.n_decay)
+        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], a.t[sl], a.tb[sl], a.n_decay, weight_decay=1.0, **kw)
+        if a.n > a.n_decay:   # biases / LN / pos / cls: same schedules, weight-decay multiplier 0
+            sl = slice(a.n_decay, a.n)
+            ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], a.t[sl], a.tb[sl], a.n - a.n_decay, weight_decay=0.0, **kw)
+        self._refresh_wn()
+        ops.center_update(self.center, self.center_sum, self.K, self.cm, 1.0 / (self.G * self.B * self.reducer.world))
+
+    def step(self, tiles_u8: torch.Tensor, **sched) -> torch.Tensor:
+        """One full training step on [B, tile, tile, 3] uint8 NHWC tiles.  Returns the
+        (device, un-synchronised) loss tensor."""
+        assert tiles_u8.shape == (self.B, self.tile, self.tile, 3) and tiles_u8.dtype == torch.uint8
+        self.set_hyper(**sched)
+        self.forward_backward(tiles_u8)
+        self.optimizer_step()
+        return self.loss
+
+    # ---- hipGraph capture of the whole step (static buffers, device-resident schedules)
+    def capture(self, tiles_u8: torch.Tensor):
+        self._static_tiles = tiles_u8.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):   # warm up on the side stream (lazy attribute setup, RCCL init)
+            self.forward_backward(self._static_tiles)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.forward_backward(self._static_tiles)
+            self.optimizer_step()
+
+    def step_graph(self, tiles_u8: Optional[torch.Tensor] = None, **sched) -> torch.Tensor:
+        if tiles_u8 is not None:
+            self._static_tiles.copy_(tiles_u8, non_blocking=True)
+        self.set_hyper(**sched)
+        self.graph.replay()
+        return self.loss
+
+
+# --------------------------------------------------------------------------- #
+# supervised single-crop step (reference train.py:1044-1078; BASELINE config 1)
+# --------------------------------------------------------------------------- #
+class SupervisedEngine:
+    """ViT + Linear head, softmax -> LabelSmoothingCE (the reference's actual loss path)."""
+
+    def __init__(self, arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999),
+                 eps=1e-8, smoothing=0.1, clip_grad: float = 0.0, mean=MEAN_RON, std=STD_RON, device="cuda:0", reducer=None):
+        dev = torch.device(device)
+        self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
+        D = ARCHS[arch]["embed_dim"]
+        self.D = D
+        self.mean, self.std = tuple(mean), tuple(std)
+        self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
+        self.W = Weights(self.arena, "")
+        self.vit = VitRunner(arch, img_size, dev)
+        self.grp = VitGroup(arch, batch, img_size, img_size, dev, save=True)
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        self.feats, self.dfeats = e((batch, D), bf16), e((batch, D), bf16)
+        self.logits, self.dlogits, self.prob = e((batch, num_classes), f32), e((batch, num_classes), f32), e((batch, num_classes), f32)
+        self.loss = torch.zeros(1, dtype=f32, device=dev)
+        self.ones = torch.ones(batch, dtype=f32, device=dev)
+        self.gnorm_sq = torch.zeros(1, dtype=f32, device=dev)
+        self.red_ws = torch.empty(1024, dtype=f32, device=dev)
+        self.lr, self.wd, self.betas, self.eps, self.smoothing, self.clip = lr, weight_decay, betas, eps, smoothing, clip_grad
+        self.t = 0
+        self.reducer = reducer if reducer is not None else NoReducer()
+
+    def load_state(self, state: Dict[str, torch.Tensor]):
+        self.arena.load(state)
+        ops.cast_bf16(self.arena.p, self.arena.pb)
+
+    def state_dict(self):
+        return self.arena.state_dict()
+
+    def grads(self):
+        return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
+
+    def forward(self, tiles_u8):
+        """Inference / features: returns (logits f32 [B,C], CLS features bf16 [B,D])."""
+        B, C, D, W = self.B, self.C, self.D, self.W
+        self.vit.forward(W, self.grp, tiles_u8, [(0, 0)], self.mean, self.std, self.feats, 0)
+        ops.small_matmul(self.feats, W.f("head.weight"), self.logits, B, C, D, sam=D, sak=1, sbk=1, sbn=D, bias=W.f("head.bias"))
+        return self.logits, self.feats
+
+    def forward_backward(self, tiles_u8, target):
+        B, C, D, W = self.B, self.C, self.D, self.W
+        self.arena.g.zero_()
+        self.forward(tiles_u8)
+        ops.softmax_lsce(self.logits, target.view(-1), self.loss, self.dlogits, self.prob, B, C, self.smoothing)
+        # head backward: dW = dlogits^T f, db = colsum(dlogits), df = dlogits W
+        ops.small_matmul(self.dlogits, self.feats, W.g("head.weight"), C, D, B, sam=1, sak=C, sbk=D, sbn=1, accumulate=True)
+        ops.small_matmul(self.ones, self.dlogits, W.g("head.bias").view(1, C), 1, C, B, sam=0, sak=1, sbk=C, sbn=1, accumulate=True)
+        ops.small_matmul(self.dlogits, W.f("head.weight"), self.dfeats, B, D, C, sam=C, sak=1, sbk=D, sbn=1)
+        self.vit.backward(W, self.grp, self.dfeats)
+        self.reducer.reduce_range(self.arena.g, 0, self.arena.n)
+        self.reducer.finish()
+
+    def optimizer_step(self, lr=None):
+        a = self.arena
+        self.t += 1
+        if self.clip > 0:
+            ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
+        kw = dict(lr=self.lr if lr is None else lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=self.t,
+                  grad_scale=1.0 / self.reducer.world, clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None)
+        sl = slice(0, a.n_decay)
+        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], None, None, a.n_decay, weight_decay=self.wd, **kw)
+        sl = slice(a.n_decay, a.n)
+        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], None, None, a.n - a.n_decay, weight_decay=0.0, **kw)
+
+    def step(self, tiles_u8, target, lr=None):
+        assert tiles_u8.dtype == torch.uint8 and target.dtype == torch.int64
+        self.forward_backward(tiles_u8, target)
+        self.optimizer_step(lr)
+        return self.loss

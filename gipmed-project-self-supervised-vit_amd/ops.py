@@ -120,8 +120,10 @@ def tokens_bwd(g, gpatch, dpos, dcls, n_img: int, N: int, D: int, accumulate: bo
     L.call("gv_tokens_bwd", a, _stream())
 
 
-def small_matmul(A, B, C, M: int, N: int, K: int, trans_a=False, accumulate=False):
-    a = L.gv_small_matmul_args(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, int(trans_a), int(accumulate))
+def small_matmul(A, B, C, M: int, N: int, K: int, *, sam, sak, sbk, sbn, ldc=None, bias=None, accumulate=False):
+    """C[m,n] (+)= sum_k A[m*sam + k*sak] B[k*sbk + n*sbn] (+ bias[n]); element strides."""
+    a = L.gv_small_matmul_args(A.data_ptr(), int(A.dtype == bf16), sam, sak, B.data_ptr(), int(B.dtype == bf16), sbk, sbn,
+                               C.data_ptr(), int(C.dtype == bf16), N if ldc is None else ldc, _p(bias), M, N, K, int(accumulate))
     L.call("gv_small_matmul", a, _stream())
 
 
@@ -143,9 +145,9 @@ def weightnorm_bwd(dw, v, g, dv, dg, rows: int, C: int, accumulate: bool):
 
 
 def dino_loss(student, teacher, center, dstudent, loss, center_sum, workspace, B: int, V: int, G: int, K: int,
-              student_temp: float, teacher_temp: float, grad_scale: float = 1.0):
+              student_temp: float, teacher_temp: float, grad_scale: float = 1.0, hyper=None):
     a = L.gv_dino_loss_args(student.data_ptr(), teacher.data_ptr(), center.data_ptr(), dstudent.data_ptr(), loss.data_ptr(),
-                            center_sum.data_ptr(), workspace.data_ptr(), B, V, G, K, student_temp, teacher_temp, grad_scale)
+                            center_sum.data_ptr(), workspace.data_ptr(), B, V, G, K, student_temp, teacher_temp, grad_scale, _p(hyper))
     L.call("gv_dino_loss", a, _stream())
 
 
@@ -172,8 +174,8 @@ def sumsq(x, workspace, out, accumulate: bool = False, n: Optional[int] = None):
 
 
 def adamw_ema(p, grad, m, v, p_bf16, teacher, teacher_bf16, n: int, *, lr, beta1, beta2, eps, weight_decay, step: int,
-              grad_scale=1.0, clip_norm=0.0, gnorm_sq=None, teacher_momentum=0.0):
+              grad_scale=1.0, clip_norm=0.0, gnorm_sq=None, teacher_momentum=0.0, hyper=None):
     a = L.gv_adamw_ema_args(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), _p(teacher), _p(teacher_bf16), n,
                             lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
-                            grad_scale, clip_norm, _p(gnorm_sq), teacher_momentum)
+                            grad_scale, clip_norm, _p(gnorm_sq), teacher_momentum, _p(hyper))
     L.call("gv_adamw_ema", a, _stream())

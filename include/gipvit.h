@@ -29,6 +29,8 @@ extern "C" {
 #endif
 
 #define GV_ABI_VERSION 1
+enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
+       GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
 enum {
     GV_OK = 0,
@@ -171,10 +173,16 @@ typedef struct {
 } gv_tokens_bwd_args;
 int gv_tokens_bwd(const gv_tokens_bwd_args* a, void* stream);
 
-/* small f32 matmul C[M,N] (+)= A[M,K] B[K,N] (bicubic pos-embed resampling,
- * vit.pyc@L213-233, expressed as a fixed linear map; trans_a uses A^T).     */
+/* small strided matmul C[m,n] (+)= sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]);
+ * element strides, each operand f32 or bf16.  For the tiny products of the path: the
+ * bicubic pos-embed resampling (vit.pyc@L213-233) as a fixed linear map, and the
+ * supervised classifier head Linear(D, num_classes) (train.py:482-495, num_classes=2). */
 typedef struct {
-    const float* A; const float* B; float* C; int32_t M, N, K; int32_t trans_a; int32_t accumulate;
+    const void* A; int32_t a_is_bf16; int64_t sam, sak;
+    const void* B; int32_t b_is_bf16; int64_t sbk, sbn;
+    void* C; int32_t c_is_bf16; int64_t ldc;
+    const float* bias;
+    int32_t M, N, K; int32_t accumulate;
 } gv_small_matmul_args;
 int gv_small_matmul(const gv_small_matmul_args* a, void* stream);
 
@@ -206,6 +214,7 @@ typedef struct {
     void* dstudent; float* loss; float* center_sum; float* workspace;
     int32_t B, V, G, K;
     float student_temp, teacher_temp, grad_scale;
+    const float* hyper;   /* optional device vector (see gv_adamw_ema_args): temps */
 } gv_dino_loss_args;
 int gv_dino_loss(const gv_dino_loss_args* a, void* stream);
 
@@ -246,6 +255,12 @@ typedef struct {
     float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2;
     float grad_scale, clip_norm; const float* gnorm_sq;
     float teacher_momentum;
+    /* optional DEVICE vector; when non-NULL it overrides the by-value scalars (except
+     * weight_decay, which then MULTIPLIES hyper[GV_HYP_WD]: 1 = decayed, 0 = not) so a
+     * captured hipGraph can be replayed with new schedules:
+     * [GV_HYP_LR, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
+     *  GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP] */
+    const float* hyper;
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
 

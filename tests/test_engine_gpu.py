@@ -1,0 +1,118 @@
+"""Whole-step parity: the HIP engine (through the C ABI) against the CPU oracle on the same
+seeded inputs and weights.  bf16 MFMA operands with f32 accumulation, f32 residual stream
+and master weights; tolerances (SURVEY 8d "parity gates", bf16 column):
+  logits  max-abs err <= 2e-2 * max|ref|,  loss |d| <= 1e-3,
+  per-parameter gradient  ||g - ref|| / ||ref|| <= 5e-2, global grad-norm rel err <= 1e-2."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _check_grads(got, ref, tol=5e-2, skip=()):
+    worst = []
+    gn_g = gn_r = 0.0
+    for k, r in ref.items():
+        if r is None or k in skip:
+            continue
+        g = got[k]
+        gn_g += float((g.double() ** 2).sum()); gn_r += float((r.double() ** 2).sum())
+        if float(r.abs().max()) < 1e-12:
+            continue
+        worst.append((_rel(g, r), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= tol, f"gradient mismatch: {worst[:8]}"
+    rel_norm = abs(math.sqrt(gn_g) - math.sqrt(gn_r)) / math.sqrt(gn_r)
+    assert rel_norm <= 1e-2, f"grad-norm rel err {rel_norm}"
+    return worst[0], rel_norm
+
+
+def test_supervised_step_parity(dev):
+    """BASELINE config 1: ViT-T/16, 64x64 tiles, single-crop supervised head, batch 8."""
+    from gipvit.engine import SupervisedEngine
+    from oracle import step_oracle as so, vit_oracle as vo
+    orc = so.SupervisedOracle(arch="vit_tiny", img_size=64, num_classes=2, seed=0, lr=1e-3, wd=0.05)
+    eng = SupervisedEngine(arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.05, device=dev)
+    eng.load_state(orc.p)
+    tiles = vo.synth_tiles(8, 64, seed=1234)
+    tgt = torch.randint(0, 2, (8, 1), generator=torch.Generator().manual_seed(5))
+    loss_r, grads_r, logits_r = orc.forward_backward(tiles, tgt)
+    eng.forward_backward(tiles.to(dev), tgt.to(dev))
+    torch.cuda.synchronize()
+    scale = float(logits_r.abs().max())
+    assert float((eng.logits.cpu() - logits_r).abs().max()) <= 2e-2 * max(scale, 1.0)
+    assert abs(float(eng.loss) - float(loss_r)) <= 1e-3
+    _check_grads(eng.grads(), grads_r)
+    # a few optimizer steps: loss trajectory
+    for i in range(5):
+        r = orc.step(tiles, tgt)
+        l = eng.step(tiles.to(dev), tgt.to(dev))
+        assert abs(float(l) - r["loss"]) <= 5e-3, (i, float(l), r["loss"])
+
+
+@pytest.mark.parametrize("n_local", [8, 0])
+def test_dino_step_parity(dev, n_local):
+    """ViT-T backbone, 2 x 224 global (+ 8 x 96 local) crops of 256-px tiles, B=2, K=4096."""
+    from gipvit.engine import DinoEngine
+    from oracle import step_oracle as so, vit_oracle as vo
+    K, B = 4096, 2
+    orc = so.DinoOracle(arch="vit_tiny", img_size=224, out_dim=K, seed=0, lr=5e-4, wd=0.04, n_local=n_local)
+    eng = DinoEngine(arch="vit_tiny", img_size=224, out_dim=K, batch=B, n_local=n_local, lr=5e-4, weight_decay=0.04, device=dev)
+    eng.load_state(orc.p, orc.hp)
+    # a non-trivial center exercises the teacher centering path
+    c = 0.05 * torch.randn(1, K, generator=torch.Generator().manual_seed(3))
+    orc.center = c.clone(); eng.center.copy_(c[0])
+    tiles = vo.synth_tiles(B, 256, seed=1234)
+    loss_r, grads_r, s_out, t_out, bsum = orc.forward_backward(tiles)
+    eng.set_hyper()
+    eng.forward_backward(tiles.to(dev))
+    torch.cuda.synchronize()
+    for got, ref, nm in ((eng.hb_t.logits, t_out, "teacher"), (eng.hb_s.logits, s_out, "student")):
+        err = float((got.cpu() - ref).abs().max())
+        assert err <= 2e-2 * float(ref.abs().max()), (nm, err, float(ref.abs().max()))
+    assert abs(float(eng.loss) - float(loss_r)) <= 1e-3, (float(eng.loss), float(loss_r))
+    assert _rel(eng.center_sum, bsum[0]) < 1e-2
+    worst, gn = _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))
+    # then full steps (optimizer + EMA + center) stay on the oracle's trajectory
+    eng.t = 0
+    for i in range(3):
+        r = orc.step(tiles)
+        l = eng.step(tiles.to(dev))
+        assert abs(float(l) - r["loss"]) <= 5e-3, (i, float(l), r["loss"])
+    torch.cuda.synchronize()
+    assert _rel(eng.center, orc.center[0]) < 1e-2
+    sd, td = eng.backbone_state_dict(), eng.backbone_state_dict(teacher=True)
+    for k in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "pos_embed", "norm.weight"):
+        assert _rel(sd[k], orc.p[k]) < 2e-2, k
+        assert _rel(td[k], orc.tp[k]) < 1e-3, k
+
+
+def test_dino_graph_replay_matches_eager(dev):
+    """The captured hipGraph step and the eager step follow the same loss trajectory."""
+    from gipvit.engine import DinoEngine
+    from oracle import step_oracle as so, vit_oracle as vo
+    K, B = 2048, 2
+    orc = so.DinoOracle(arch="vit_tiny", img_size=224, out_dim=K, seed=0)
+    tiles = vo.synth_tiles(B, 256, seed=7).to(dev)
+    losses = []
+    for mode in ("eager", "graph"):
+        eng = DinoEngine(arch="vit_tiny", img_size=224, out_dim=K, batch=B, device=dev)
+        eng.load_state(orc.p, orc.hp)
+        if mode == "graph":
+            eng.capture(tiles)
+            eng.load_state(orc.p, orc.hp)      # capture warm-up ran forward/backward only; reset anyway
+            eng.arena.m.zero_(); eng.arena.v.zero_(); eng.center.zero_(); eng.t = 0
+        ls = []
+        for _ in range(4):
+            l = eng.step_graph(tiles) if mode == "graph" else eng.step(tiles)
+            ls.append(float(l))
+        losses.append(ls)
+    for a, b in zip(*losses):
+        assert abs(a - b) < 5e-3, losses

@@ -323,10 +323,10 @@ def test_tokens_and_misc(dev):
     close(y, gv[:, 0], 8e-3, 1e-3, "gather cls")
     A = torch.randn(36, 196, generator=g).to(dev); Bm = torch.randn(196, D, generator=g).to(dev)
     C = torch.empty(36, D, device=dev)
-    o.small_matmul(A, Bm, C, 36, D, 196)
+    o.small_matmul(A, Bm, C, 36, D, 196, sam=196, sak=1, sbk=D, sbn=1)
     close(C, A @ Bm, 1e-4, 1e-4, "small matmul")
     C2 = torch.ones(196, D, device=dev); Bt = torch.randn(36, D, generator=g).to(dev)
-    o.small_matmul(A, Bt, C2, 196, D, 36, trans_a=True, accumulate=True)
+    o.small_matmul(A, Bt, C2, 196, D, 36, sam=1, sak=196, sbk=D, sbn=1, accumulate=True)
     close(C2, 1 + A.t() @ Bt, 1e-4, 1e-4, "small matmul T")
     n = 1_000_003
     src = torch.randn(n, generator=g).to(dev); dst = torch.empty(n, dtype=bf16, device=dev)
