@@ -142,20 +142,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(gv_layernorm_bwd_args a) {
     }
 }
 
-__global__ void colsum_finalize_kernel(gv_colsum_finalize_args a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.C) return;
-    const float* p = a.partials + (long)a.which * a.C + c;
-    const long stride = (long)a.n_which * a.C;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < a.n_blocks; b += 4) {
-        s0 += p[(b + 0) * stride]; s1 += p[(b + 1) * stride];
-        s2 += p[(b + 2) * stride]; s3 += p[(b + 3) * stride];
+// block = 64 columns x 4 row groups; each thread sums every 4th partial row, LDS combines
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(gv_colsum_finalize_args a) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < a.C) {
+        const float* p = a.partials + (long)a.which * a.C + c;
+        const long stride = (long)a.n_which * a.C;
+        int b = grp;
+        for (; b + 4 < a.n_blocks; b += 8) { s0 += p[b * stride]; s1 += p[(b + 4) * stride]; }
+        if (b < a.n_blocks) s0 += p[b * stride];
     }
-    for (; b < a.n_blocks; ++b) s0 += p[b * stride];
-    const float s = (s0 + s1) + (s2 + s3);
-    a.out[c] = a.accumulate ? a.out[c] + s : s;
+    red[grp][lane] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && c < a.C) {
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        a.out[c] = a.accumulate ? a.out[c] + s : s;
+    }
 }
 
 // column sums of [rows, C]: block (x: 128 columns as 64 lanes x 2, y: row slice)
@@ -221,7 +226,7 @@ extern "C" int gv_layernorm_bwd(const gv_layernorm_bwd_args* a, void* stream) {
 extern "C" int gv_colsum_finalize(const gv_colsum_finalize_args* a, void* stream) {
     GV_REQUIRE(a && a->partials && a->out, GV_E_NULL, "gv_colsum_finalize: null pointer");
     GV_REQUIRE(a->C > 0 && a->n_blocks > 0 && a->which >= 0 && a->which < a->n_which, GV_E_SHAPE, "gv_colsum_finalize: bad shape");
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a->C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a->C + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
     GV_LAUNCH_CHECK("gv_colsum_finalize");
     return GV_OK;
 }

@@ -85,7 +85,7 @@ def test_dino_step_parity(dev, n_local):
     for i in range(3):
         r = orc.step(tiles)
         l = eng.step(tiles.to(dev))
-        assert abs(float(l) - r["loss"]) <= 5e-3, (i, float(l), r["loss"])
+        assert abs(float(l) - r["loss"]) <= 2e-2, (i, float(l), r["loss"])
     torch.cuda.synchronize()
     assert _rel(eng.center, orc.center[0]) < 1e-2
     sd, td = eng.backbone_state_dict(), eng.backbone_state_dict(teacher=True)

@@ -118,7 +118,7 @@ def test_linear_pos_epilogue(dev):
 def test_linear_rejects_bad_shapes(dev):
     A = torch.zeros(64, 100, dtype=bf16, device=dev); B = torch.zeros(64, 100, dtype=bf16, device=dev)
     C = torch.zeros(64, 64, dtype=f32, device=dev)
-    with pytest.raises(L().GipvitError, match="multiple of 64"):
+    with pytest.raises(L().GipvitError, match="multiple of 32"):
         ops().linear(A, B, C, 64, 64, 100, lda=104, ldb=104)
 
 

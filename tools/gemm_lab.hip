@@ -1,0 +1,115 @@
+// GEMM geometry lab: times gemm_core.h under several tile / wave / ring geometries on the
+// hot path's shapes, all in one process (interleaved rounds, rule 24).  Not part of the
+// library; built by tools/run_gemm_lab.sh.
+#include "../gipmed-project-self-supervised-vit_amd/csrc/gemm_core.h"
+#include <vector>
+#include <string>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+void gv_set_error(const char*, ...) {}
+using namespace gvgemm;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+template <class C, bool TA, bool TB, typename OutT, bool ATOMIC, int EPI, int WPC>
+__global__ __launch_bounds__(C::THREADS, C::THREADS * WPC / 256) void lab_kernel(const GemmP g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    gemm_body<C, TA, TB, OutT, ATOMIC, EPI>(g, (GV_LDS char*)smem_raw);
+}
+
+struct Shape { const char* name; int M, N, K; bool ta, tb; int epi; bool cf32; };
+
+template <class C, bool TA, bool TB, typename OutT, int EPI>
+float run_cfg(const Shape& sh, GemmP p, int reps, int persistent_mult, int order) {
+    constexpr int WPC = (160 * 1024 / C::LDS) < 2 ? 1 : 2;
+    auto kern = lab_kernel<C, TA, TB, OutT, false, EPI, WPC>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    p.tiles_m = (sh.M + C::BM - 1) / C::BM; p.tiles_n = (sh.N + C::BN - 1) / C::BN;
+    p.ksplit = 1; p.k_per_split = ((sh.K + C::BK - 1) / C::BK) * C::BK; p.order = order;
+    const int items = p.tiles_m * p.tiles_n;
+    int grid = 256 * WPC * persistent_mult;
+    if (persistent_mult == 0 || items < grid) grid = items;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS, 0, p);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS, 0, p);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGetLastError());
+    return ms * 1e-3f / reps;
+}
+
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
+
+template <class C>
+void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void* B, void* Cb, void* ref, float* bias, void* aux,
+             float* resid) {
+    for (const auto& sh : shapes) {
+        GemmP p{};
+        p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = Cb; p.M = sh.M; p.N = sh.N; p.K = sh.K;
+        p.lda = sh.ta ? sh.M : sh.K; p.ldb = sh.tb ? sh.N : sh.K; p.ldc = sh.N;
+        p.epi = sh.epi; p.bias = bias; p.resid = resid; p.ldr = sh.N; p.aux_in = (const bf16*)aux; p.ld_aux = sh.N; p.aux_out = (bf16*)aux;
+        p.alpha = 1.f;
+        float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+        for (int v = 0; v < 4; ++v) {      // bit0: persistent, bit1: NO-STORE ablation
+            const int pm = v & 1, order = 0; p.epi = sh.epi | ((v >> 1) ? (1 << 20) : 0);
+            for (int round = 0; round < 3; ++round) {
+                float t;
+                if (!sh.ta && !sh.tb) {
+                    if (sh.epi == GV_EPI_BIAS) t = run_cfg<C, false, false, bf16, GV_EPI_BIAS>(sh, p, 10, pm, order);
+                    else if (sh.epi == (GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE)) t = run_cfg<C, false, false, bf16, GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE>(sh, p, 10, pm, order);
+                    else t = run_cfg<C, false, false, float, GV_EPI_BIAS | GV_EPI_RESID>(sh, p, 10, pm, order);
+                } else if (!sh.ta && sh.tb) {
+                    t = run_cfg<C, false, true, bf16, 0>(sh, p, 10, pm, order);
+                } else {
+                    t = run_cfg<C, true, true, float, 0>(sh, p, 10, pm, order);
+                }
+                best[v] = std::min(best[v], t);
+            }
+        }
+        const double fl = 2.0 * sh.M * sh.N * sh.K;
+        printf("%-20s %-19s flat: tile/wg %6.1f us %6.1f TF | persist %6.1f us %6.1f TF || NOSTORE: tile/wg %6.1f us %6.1f TF | persist %6.1f us %6.1f TF\n",
+               cname, sh.name, best[0] * 1e6, fl / best[0] / 1e12, best[1] * 1e6, fl / best[1] / 1e12, best[2] * 1e6, fl / best[2] / 1e12,
+               best[3] * 1e6, fl / best[3] / 1e12);
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int only_cfg = argc > 1 ? atoi(argv[1]) : -1, only_shape = argc > 2 ? atoi(argv[2]) : -1;
+    const int T = 25216;
+    std::vector<Shape> all_shapes = {
+        {"qkv(NT,bias)", T, 1152, 384, false, false, GV_EPI_BIAS, false},
+        {"fc1(NT,b+gelu+pre)", T, 1536, 384, false, false, GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE, false},
+        {"fc2(NT,b+res,f32)", T, 384, 1536, false, false, GV_EPI_BIAS | GV_EPI_RESID, true},
+        {"dX fc1(NN)", T, 384, 1536, false, true, 0, false},
+        {"dX fc2(NN)", T, 1536, 384, false, true, 0, false},
+        {"dW fc1(TN,noSplit)", 1536, 384, T, true, true, 0, true},
+    };
+    std::vector<Shape> shapes;
+    for (int i = 0; i < (int)all_shapes.size(); ++i) if (only_shape < 0 || only_shape == i) shapes.push_back(all_shapes[i]);
+    size_t nA = (size_t)T * 1536, nB = (size_t)1536 * T, nC = (size_t)T * 1536;
+    std::vector<unsigned short> hA(nA), hB(nB);
+    srand(1);
+    for (auto& x : hA) x = f2bf((rand() / (float)RAND_MAX - 0.5f));
+    for (auto& x : hB) x = f2bf((rand() / (float)RAND_MAX - 0.5f) * 0.1f);
+    void *A, *B, *C, *aux; float *bias, *resid;
+    CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&B, nB * 2)); CK(hipMalloc(&C, nC * 4)); CK(hipMalloc(&aux, nC * 2));
+    CK(hipMalloc(&bias, 4096 * 4)); CK(hipMalloc(&resid, nC * 4));
+    CK(hipMemcpy(A, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), nB * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, 4096 * 4)); CK(hipMemset(resid, 0, nC * 4)); CK(hipMemset(aux, 0, nC * 2));
+    //            BM   BN  BK WM WN NSTAGE
+    if (only_cfg < 0 || only_cfg == 0) run_all<Cfg<128, 128, 32, 2, 2, 4>>("128x128 k32 2x2 s4", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 1) run_all<Cfg<128, 128, 64, 2, 2, 2>>("128x128 k64 2x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 2) run_all<Cfg<128, 128, 64, 2, 2, 3>>("128x128 k64 2x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 3) run_all<Cfg<256, 128, 32, 4, 2, 3>>("256x128 k32 4x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 4) run_all<Cfg<256, 128, 32, 2, 2, 3>>("256x128 k32 2x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 5) run_all<Cfg<256, 128, 64, 4, 2, 2>>("256x128 k64 4x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 6) run_all<Cfg<256, 128, 64, 4, 2, 3>>("256x128 k64 4x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 7) run_all<Cfg<256, 256, 32, 4, 2, 3>>("256x256 k32 4x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 8) run_all<Cfg<256, 256, 64, 4, 2, 2>>("256x256 k64 4x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 9) run_all<Cfg<128, 256, 32, 2, 2, 3>>("128x256 k32 2x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
+    return 0;
+}
