@@ -32,6 +32,8 @@ gv_layernorm_bwd_args = _struct("gv_layernorm_bwd_args", [
     ("rows", i32), ("D", i32), ("g_init", i32)])
 gv_colsum_finalize_args = _struct("gv_colsum_finalize_args", [
     ("partials", vp), ("n_blocks", i32), ("n_which", i32), ("which", i32), ("C", i32), ("out", vp), ("accumulate", i32)])
+gv_ln_finalize_args = _struct("gv_ln_finalize_args", [
+    ("partials", vp), ("n_blocks", i32), ("C", i32), ("out0", vp), ("out1", vp), ("out2", vp)])
 gv_colsum_args = _struct("gv_colsum_args", [
     ("x", vp), ("x_is_f32", i32), ("ld", i64), ("rows", i32), ("C", i32), ("workspace", vp), ("out", vp), ("accumulate", i32)])
 gv_linear_args = _struct("gv_linear_args", [
@@ -71,7 +73,7 @@ gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
 # entry point -> argument struct (every `int gv_*(const args*, void* stream)` of the header)
 ENTRY_POINTS = {
     "gv_patchify": gv_patchify_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
-    "gv_colsum_finalize": gv_colsum_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
+    "gv_colsum_finalize": gv_colsum_finalize_args, "gv_ln_finalize": gv_ln_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
     "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_cls_rows": gv_cls_rows_args,
     "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,

@@ -222,6 +222,51 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
 #pragma unroll
         for (int s = 0; s < PD; ++s) issue();
 
+        // ---- epilogue geometry (see below) and EARLY PREFETCH of its global operands: the
+        // residual / pos / accumulate-into values and the saved pre-activation are loaded into
+        // registers now, so their HBM latency hides under the whole k-loop instead of being
+        // paid once per row block after it.
+        const int m0 = it.m0 + wm * FM * 16, n0 = it.n0 + wn * FN * 16;
+        constexpr int IW = FN * 16;                     // image width (columns of this wave)
+        constexpr int STRIDE = IW + 4;                  // f32 row stride, +4 breaks bank conflicts
+        constexpr int ROWS_FIT = (C::LDS / C::NW) / (STRIDE * 4);
+        constexpr int IB = ROWS_FIT >= FM * 16 ? FM : (ROWS_FIT >= 32 && FM % 2 == 0 ? 2 : 1);   // 16-row blocks per pass
+        static_assert(16 * STRIDE * 4 <= C::LDS / C::NW, "one 16-row block of the image must fit the wave's share");
+        constexpr int W = ATOMIC ? 1 : OutVec<OutT>::W;     // columns per lane in the row pass
+        constexpr int LPR = IW / W;                          // lanes per image row
+        constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;        // image rows per wave-instruction
+        constexpr int CPI = LPR > 64 ? LPR / 64 : 1;         // column chunks when a row needs > 64 lanes
+        constexpr int NIT = FM * 16 / RPI * CPI;             // row-pass iterations per tile
+        const int lrow = LPR >= 64 ? 0 : lane / LPR;
+        const int lcol = (LPR >= 64 ? lane : lane % LPR) * W;
+        const int epi = EPI >= 0 ? EPI : g.epi;
+        const int N = g.N, M = g.M;
+        constexpr bool PREFETCH = !ATOMIC && EPI >= 0 && (EPI & (GV_EPI_RESID | GV_EPI_POS | GV_EPI_ACCUM | GV_EPI_DGELU)) != 0;
+        f32x4 pre_r[PREFETCH ? NIT : 1][W / 4 > 0 ? W / 4 : 1];
+        bf16x8 pre_a[PREFETCH && (EPI >= 0 && (EPI & GV_EPI_DGELU)) ? NIT : 1];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int itn = 0; itn < NIT; ++itn) {
+                const int row = (itn / CPI) * RPI + lrow, col = lcol + (itn % CPI) * 64 * W;
+                const int m = m0 + row, n = n0 + col;
+                const int mc = m < M ? m : M - 1, nc = n < N ? n : N - W;
+                long orow = mc; int prow = 0;
+                if (EPI & GV_EPI_POS) { orow = mc + mc / g.P + 1; prow = (mc % g.P) + 1; }
+#pragma unroll
+                for (int q = 0; q < W; q += 4) {
+                    f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (EPI & GV_EPI_RESID) r += *(const f32x4*)(g.resid + orow * g.ldr + nc + q);
+                    if (EPI & GV_EPI_POS) r += *(const f32x4*)(g.pos + (long)prow * N + nc + q);
+                    if constexpr (sizeof(OutT) == 4) { if (EPI & GV_EPI_ACCUM) r += *(const f32x4*)((const float*)g.C + orow * g.ldc + nc + q); }
+                    pre_r[itn][q / 4] = r;
+                }
+                if constexpr ((EPI & GV_EPI_DGELU) != 0) {
+                    if constexpr (W == 8) pre_a[itn] = *(const bf16x8*)(g.aux_in + orow * g.ld_aux + nc);
+                    else { const bf16x4 a = *(const bf16x4*)(g.aux_in + orow * g.ld_aux + nc); pre_a[itn] = bf16x8{a[0], a[1], a[2], a[3], a[0], a[1], a[2], a[3]}; }
+                }
+            }
+        }
+
         f32x4 acc[FM][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -241,19 +286,27 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             __builtin_amdgcn_s_barrier();     // everybody's pieces landed; last step's stage is free
             issue();
             GV_LDS char* cur = smem + c_stage * C::STAGE;
+            // all fragment reads of the stage are issued up front (KS * (FM + FN) ds_read_b128 /
+            // tr reads); the MFMAs then run back-to-back behind the compiler's counted lgkmcnt(N)
+            // instead of exposing the LDS latency once per small read group.
+            bf16x8 fa[C::KS][FM], fb[C::KS][FN];
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
-                bf16x8 fa[FM], fb[FN];
 #pragma unroll
-                for (int i = 0; i < FM; ++i) fa[i] = read_frag<TA, BM, BK>(cur, wm * FM + i, ks, lane);
+                for (int j = 0; j < FN; ++j) fb[ks][j] = read_frag<TB, BN, BK>(cur + C::A_BYTES, wn * FN + j, ks, lane);
 #pragma unroll
-                for (int j = 0; j < FN; ++j) fb[j] = read_frag<TB, BN, BK>(cur + C::A_BYTES, wn * FN + j, ks, lane);
+                for (int i = 0; i < FM; ++i) fa[ks][i] = read_frag<TA, BM, BK>(cur, wm * FM + i, ks, lane);
+            }
+#ifdef GV_GEMM_PIN_READS
+            __builtin_amdgcn_sched_barrier(0);   // keep every read ahead of the first MFMA
+#endif
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
             c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
         }
         __builtin_amdgcn_s_barrier();   // every wave is done reading the ring: it is epilogue scratch now
@@ -262,27 +315,13 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         // The accumulators go through a per-wave LDS image so that every lane ends up with
         // ROW-CONTIGUOUS columns: bias / residual / aux loads and all stores (and atomics) are
         // then whole 128..256-B row segments instead of 16 scattered 32-B pieces per instruction.
-        const int m0 = it.m0 + wm * FM * 16, n0 = it.n0 + wn * FN * 16;
-        constexpr int IW = FN * 16;                     // image width (columns of this wave)
-        constexpr int STRIDE = IW + 4;                  // f32 row stride, +4 breaks bank conflicts
         GV_LDS float* img = (GV_LDS float*)(smem + wave * (C::LDS / C::NW));
-        static_assert(16 * STRIDE * 4 <= C::LDS / C::NW, "one 16-row block of the image must fit the wave's share");
-        constexpr int ROWS_FIT = (C::LDS / C::NW) / (STRIDE * 4);
-        constexpr int IB = ROWS_FIT >= FM * 16 ? FM : (ROWS_FIT >= 32 && FM % 2 == 0 ? 2 : 1);   // 16-row blocks per pass
         float* Cf = (float*)g.C;
         OutT* Cp = (OutT*)g.C;
-        const int epi = EPI >= 0 ? EPI : g.epi;
-        const int N = g.N, M = g.M;
         bool vec_path = true;
         if constexpr (EPI < 0 && !ATOMIC) vec_path = (N & 7) == 0;
 
         if (ATOMIC || vec_path) {
-            constexpr int W = ATOMIC ? 1 : OutVec<OutT>::W;     // columns per lane in the row pass
-            constexpr int LPR = IW / W;                          // lanes per image row
-            constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;        // image rows per wave-instruction
-            constexpr int CPI = LPR > 64 ? LPR / 64 : 1;         // column chunks when a row needs > 64 lanes
-            const int lrow = LPR >= 64 ? 0 : lane / LPR;
-            const int lcol = (LPR >= 64 ? lane : lane % LPR) * W;
 #pragma unroll
             for (int ib = 0; ib < FM; ib += IB) {
 #pragma unroll
@@ -299,6 +338,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
                     for (int cc = 0; cc < CPI; ++cc) {
                         const int row = r0 + lrow, col = lcol + cc * 64 * W;
                         const int m = m0 + ib * 16 + row, n = n0 + col;
+                        const int itn = ((ib * 16 + r0) / RPI) * CPI + cc;   // compile-time after unrolling
                         const bool ok = m < M && n < N;
                         if constexpr (ATOMIC) {
                             if (ok) atomicAdd(Cf + (long)m * g.ldc + n, img[row * STRIDE + col]);
@@ -327,22 +367,22 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
                                 for (int q = 0; q < W; ++q) v[q] = gelu_f(v[q]);
                             }
                             if (epi & GV_EPI_DGELU) {
-                                if constexpr (W == 8) {
-                                    const bf16x8 a = *(const bf16x8*)(g.aux_in + orow * g.ld_aux + nc);
+                                bf16x8 a;
+                                if constexpr (PREFETCH) a = pre_a[(EPI >= 0 && (EPI & GV_EPI_DGELU)) ? itn : 0];
+                                else if constexpr (W == 8) a = *(const bf16x8*)(g.aux_in + orow * g.ld_aux + nc);
+                                else { const bf16x4 a4 = *(const bf16x4*)(g.aux_in + orow * g.ld_aux + nc); a = bf16x8{a4[0], a4[1], a4[2], a4[3], a4[0], a4[1], a4[2], a4[3]}; }
 #pragma unroll
-                                    for (int q = 0; q < 8; ++q) v[q] *= dgelu_f((float)a[q]);
-                                } else {
-                                    const bf16x4 a = *(const bf16x4*)(g.aux_in + orow * g.ld_aux + nc);
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) v[q] *= dgelu_f((float)a[q]);
-                                }
+                                for (int q = 0; q < W; ++q) v[q] *= dgelu_f((float)a[q]);
                             }
 #pragma unroll
                             for (int q = 0; q < W; q += 4) {
                                 f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
-                                if (epi & GV_EPI_RESID) r += *(const f32x4*)(g.resid + orow * g.ldr + nc + q);
-                                if (epi & GV_EPI_POS) r += *(const f32x4*)(g.pos + (long)prow * N + nc + q);
-                                if constexpr (sizeof(OutT) == 4) { if (epi & GV_EPI_ACCUM) r += *(const f32x4*)(Cf + orow * g.ldc + nc + q); }
+                                if constexpr (PREFETCH) r = pre_r[itn][q / 4];
+                                else {
+                                    if (epi & GV_EPI_RESID) r += *(const f32x4*)(g.resid + orow * g.ldr + nc + q);
+                                    if (epi & GV_EPI_POS) r += *(const f32x4*)(g.pos + (long)prow * N + nc + q);
+                                    if constexpr (sizeof(OutT) == 4) { if (epi & GV_EPI_ACCUM) r += *(const f32x4*)(Cf + orow * g.ldc + nc + q); }
+                                }
                                 v[q] += r[0]; v[q + 1] += r[1]; v[q + 2] += r[2]; v[q + 3] += r[3];
                             }
                             if (g.epi & (1 << 20)) { asm volatile("" ::"v"(v[0]), "v"(v[W - 1])); }   // lab ablation: no store

@@ -163,6 +163,26 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(gv_colsum_finalize
     }
 }
 
+// grid (C/64, 3 outputs, 8 row slices): 144+ blocks instead of 6; slices meet through atomics
+__global__ __launch_bounds__(256) void ln_finalize_kernel(gv_ln_finalize_args a) {
+    __shared__ float red[4][64];
+    float* out = blockIdx.y == 0 ? a.out0 : blockIdx.y == 1 ? a.out1 : a.out2;
+    if (!out) return;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int per = (a.n_blocks + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(a.n_blocks, b0 + per);
+    float s = 0.f;
+    if (c < a.C) {
+        const float* p = a.partials + (long)blockIdx.y * a.C + c;
+        const long stride = 3L * a.C;
+        for (int b = b0 + grp; b < b1; b += 4) s += p[b * stride];
+    }
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < a.C) atomicAdd(out + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
 // column sums of [rows, C]: block (x: 128 columns as 64 lanes x 2, y: row slice)
 template <bool F32>
 __global__ __launch_bounds__(256) void colsum_kernel(gv_colsum_args a) {
@@ -228,6 +248,14 @@ extern "C" int gv_colsum_finalize(const gv_colsum_finalize_args* a, void* stream
     GV_REQUIRE(a->C > 0 && a->n_blocks > 0 && a->which >= 0 && a->which < a->n_which, GV_E_SHAPE, "gv_colsum_finalize: bad shape");
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a->C + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
     GV_LAUNCH_CHECK("gv_colsum_finalize");
+    return GV_OK;
+}
+
+extern "C" int gv_ln_finalize(const gv_ln_finalize_args* a, void* stream) {
+    GV_REQUIRE(a && a->partials, GV_E_NULL, "gv_ln_finalize: null pointer");
+    GV_REQUIRE(a->C > 0 && a->n_blocks > 0, GV_E_SHAPE, "gv_ln_finalize: bad shape");
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((a->C + 63) / 64, 3, 8), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_ln_finalize");
     return GV_OK;
 }
 

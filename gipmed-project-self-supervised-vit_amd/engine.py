@@ -240,8 +240,8 @@ class VitRunner:
         ops.layernorm_fwd(xl, W.f("norm.weight"), W.f("norm.bias"), G.n_img, D, x_stride=N * D,
                           y=feats[row_off:row_off + G.n_img], mean=G.fstats[0], rstd=G.fstats[1])
 
-    def _fin(self, which: int, out: torch.Tensor):
-        ops.colsum_finalize(self.partials, L.LN_PARTIAL_BLOCKS, 3, which, self.D, out, True)
+    def _fin3(self, dgamma, dbeta, dbias):
+        ops.ln_finalize(self.partials, L.LN_PARTIAL_BLOCKS, self.D, dgamma, dbeta, dbias)
 
     # ---- backward from d(CLS features) bf16 [n_img, D]; gradients ACCUMULATE into the arena
     def backward(self, W: Weights, G: VitGroup, dfeat: torch.Tensor):
@@ -252,8 +252,7 @@ class VitRunner:
         xl = G.x[2 * self.depth]
         ops.layernorm_bwd(dfeat, xl, G.fstats[0], G.fstats[1], W.f("norm.weight"), G.g, G.gb, self.partials, G.n_img, D,
                           x_stride=N * D, g_stride=N * D, gb_stride=N * D, g_init=True)
-        self._fin(0, W.g("norm.weight")); self._fin(1, W.g("norm.bias"))
-        self._fin(2, W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
+        self._fin3(W.g("norm.weight"), W.g("norm.bias"), W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
         for i in reversed(range(self.depth)):
             b, st = f"blocks.{i}.", G.stats[i]
             # MLP
@@ -263,7 +262,7 @@ class VitRunner:
             ops.linear(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
             ops.colsum(G.dh, T, 4 * D, self.cs_ws, W.g(b + "mlp.fc1.bias"), accumulate=True)
             ops.layernorm_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), G.g, G.gb, self.partials, T, D)
-            self._fin(0, W.g(b + "norm2.weight")); self._fin(1, W.g(b + "norm2.bias")); self._fin(2, W.g(b + "attn.proj.bias"))
+            self._fin3(W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"))
             # attention
             ops.linear(G.gb, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             ops.linear(G.gb, G.o[i], W.g(b + "attn.proj.weight"), D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
@@ -272,9 +271,7 @@ class VitRunner:
             ops.linear(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
             ops.colsum(G.dqkv, T, 3 * D, self.cs_ws, W.g(b + "attn.qkv.bias"), accumulate=True)
             ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, G.gb, self.partials, T, D)
-            self._fin(0, W.g(b + "norm1.weight")); self._fin(1, W.g(b + "norm1.bias"))
-            if i > 0:
-                self._fin(2, W.g(f"blocks.{i - 1}.mlp.fc2.bias"))
+            self._fin3(W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
         # token assembly + patch embedding
         ops.tokens_bwd(G.g, G.gpatch, G.dpos, None, G.n_img, N, D, accumulate=False)
         # d cls_token = sum over images of the CLS-row gradient = dpos row 0

@@ -73,6 +73,11 @@ def colsum_finalize(partials, n_blocks: int, n_which: int, which: int, C: int, o
     L.call("gv_colsum_finalize", a, _stream())
 
 
+def ln_finalize(partials, n_blocks: int, C: int, out0, out1, out2):
+    """out_w += column sums of partials[:, w, :] (w = 0, 1, 2); None outputs are skipped."""
+    L.call("gv_ln_finalize", L.gv_ln_finalize_args(partials.data_ptr(), n_blocks, C, _p(out0), _p(out1), _p(out2)), _stream())
+
+
 def colsum(x, rows: int, C: int, workspace, out, accumulate: bool = False, ld: Optional[int] = None):
     a = L.gv_colsum_args(x.data_ptr(), int(x.dtype == f32), C if ld is None else ld, rows, C, workspace.data_ptr(),
                          out.data_ptr(), int(accumulate))

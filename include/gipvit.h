@@ -101,6 +101,15 @@ typedef struct {
 } gv_colsum_finalize_args;
 int gv_colsum_finalize(const gv_colsum_finalize_args* a, void* stream);
 
+/* all three column sums of a LayerNorm-backward partial buffer in one launch:
+ * out_w[c] += sum_b partials[b, w, c] for w = 0..2 (NULL outputs are skipped).  Always
+ * accumulates (row-split blocks meet in the outputs through f32 atomics).             */
+typedef struct {
+    const float* partials; int32_t n_blocks, C;
+    float* out0; float* out1; float* out2;
+} gv_ln_finalize_args;
+int gv_ln_finalize(const gv_ln_finalize_args* a, void* stream);
+
 /* column sums of a bf16 or f32 matrix [rows, C] -> out[C] f32 (bias grads,
  * train.py:1071 backward of nn.Linear bias).  workspace >= 64*C floats.    */
 typedef struct {

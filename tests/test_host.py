@@ -1,0 +1,119 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gipvit.h declares (no
+compute calls without a GPU), the ctypes structs have the header's layout, host-side logic
+(arena layout, model registry, init, checkpoint I/O, reducer over gloo)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gipvit import _lib
+    hdr = open(os.path.join(ROOT, "include", "gipvit.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(gv_\w+)\s*\(", hdr, re.M))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(_lib.lib, name), f"{name} declared in gipvit.h but not exported"
+    bound = set(_lib.ENTRY_POINTS) | set(_lib.PLAIN_SYMBOLS)
+    assert declared == bound, (declared - bound, bound - declared)
+    assert _lib.lib.gv_version() == 1 and _lib.lib.gv_target() == b"gfx950"
+
+
+def test_struct_layout_matches_header():
+    """sizeof of every args struct as the C compiler sees it == ctypes' view."""
+    from gipvit import _lib
+    names = sorted(s.__name__ for s in _lib.ENTRY_POINTS.values())
+    src = '#include <stdio.h>\n#include "gipvit.h"\nint main(){' + "".join(
+        f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
+    exe = os.path.join(ROOT, "gpurun_out", "_sizeof_test")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    r = subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    out = dict(l.split() for l in subprocess.run([exe], capture_output=True, text=True).stdout.splitlines())
+    for st in _lib.ENTRY_POINTS.values():
+        assert int(out[st.__name__]) == ctypes.sizeof(st), st.__name__
+
+
+def test_bad_arguments_fail_loudly_without_gpu():
+    """Argument validation happens before any launch: errors come back through the ABI."""
+    from gipvit import _lib
+    a = _lib.gv_linear_args()          # all NULL
+    rc = _lib.lib.gv_linear(ctypes.byref(a), None)
+    assert rc == -3 and b"null" in _lib.lib.gv_last_error()
+    b = _lib.gv_layernorm_fwd_args(1, 100, 1, 1, 1, 1, 1, 4, 100, 1e-6)
+    assert _lib.lib.gv_layernorm_fwd(ctypes.byref(b), None) == -1 and b"192" in _lib.lib.gv_last_error()
+
+
+def test_arena_layout_and_decay_split():
+    from collections import OrderedDict
+    from gipvit import engine as E
+    specs = OrderedDict(("backbone." + k, v) for k, v in E.vit_param_specs("vit_tiny", 64, 0).items())
+    specs.update(("head." + k, v) for k, v in E.dino_head_specs(192, 256).items())
+    a = E.Arena(specs, "cpu", teacher=True)
+    assert a.n % 64 == 0 and a.n_decay % 64 == 0
+    for n in specs:
+        assert a.off[n] % 64 == 0
+        assert (a.off[n] < a.n_decay) == (not E.no_weight_decay(n, specs[n])), n
+    # gradients complete head-first: the head's matrices open the arena, patch embed closes the decayed part
+    assert a.order[0] == "head.last_layer.weight_v" and a.order.index("backbone.blocks.11.mlp.fc2.weight") < a.order.index("backbone.blocks.0.attn.qkv.weight")
+    assert E.no_weight_decay("backbone.pos_embed", (1, 17, 192)) and E.no_weight_decay("head.last_layer.weight_g", (256, 1))
+    assert not E.no_weight_decay("backbone.patch_embed.proj.weight", (192, 3, 16, 16))
+    a.view(a.p, "backbone.norm.weight").fill_(3.0)
+    assert float(a.state_dict(prefix="backbone.")["norm.weight"].mean()) == 3.0
+
+
+def test_model_registry_init_and_checkpoint_roundtrip(tmp_path):
+    from gipvit import models as M
+    assert M.resolve_arch("vit_small_patch16_224_dino") == "vit_small"
+    with pytest.raises(ValueError):
+        M.resolve_arch("resnet50")
+    sd = M.init_vit_state("vit_tiny", 64, 2, seed=0)
+    assert sd["pos_embed"].shape == (1, 17, 192) and sd["head.weight"].shape == (2, 192)
+    assert float(sd["blocks.3.norm1.weight"].min()) == 1.0 and float(sd["blocks.3.attn.qkv.bias"].abs().max()) == 0.0
+    assert 0.015 < float(sd["blocks.0.mlp.fc1.weight"].std()) < 0.025 and float(sd["blocks.0.mlp.fc1.weight"].abs().max()) <= 2.0
+    # timm-style file: {'state_dict': {'module.<name>': ...}}, 224-px pos-embed into a 64-px model
+    big = M.init_vit_state("vit_tiny", 224, 0, seed=1)
+    path = tmp_path / "model_best.pth.tar"
+    torch.save({"epoch": 3, "arch": "vit_tiny_patch16_224", "state_dict": {"module." + k: v for k, v in big.items()}, "version": 2}, path)
+    got = M.load_encoder_checkpoint(str(path), "vit_tiny", 64, num_classes=2)
+    assert got["pos_embed"].shape == (1, 17, 192) and torch.equal(got["blocks.5.mlp.fc2.weight"], big["blocks.5.mlp.fc2.weight"])
+    assert got["head.weight"].shape == (2, 192)            # missing head -> freshly initialised
+    assert torch.equal(got["pos_embed"][:, 0], big["pos_embed"][:, 0])
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gipvit.dist import RcclReducer, shard_range
+    red = RcclReducer()
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    c = torch.full((16,), float(rank + 1))
+    red.reduce_tensor(c)
+    red.reduce_range(g, 0, 384)          # head range first, as the engine does
+    red.reduce_range(g, 384, 1000)
+    red.finish()
+    q.put((rank, g.clone(), c.clone(), shard_range(64, rank, world)))
+    dist.destroy_process_group()
+
+
+def test_reducer_world_size_2_gloo():
+    """N > 1 path on CPU: ranged all-reduces of the flat gradient arena + center sum."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    for rank, g, c, shard in res:
+        assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)   # (1 + 2) x
+        assert torch.equal(c, torch.full((16,), 3.0))
+        assert shard == (32 * rank, 32 * rank + 32)

@@ -150,6 +150,11 @@ def test_layernorm_fwd_bwd(dev, D):
     close(outs[0], gr.grad, 1e-3, 1e-2, "dgamma")
     close(outs[1], br.grad, 1e-3, 1e-2, "dbeta")
     close(outs[2], (g0 + xr.grad).sum(0), 1e-3, 1e-2, "colsum g")
+    o3 = [torch.ones(D, device=dev) for _ in range(3)]
+    o.ln_finalize(partials, L().LN_PARTIAL_BLOCKS, D, o3[0], None, o3[2])
+    close(o3[0], 1 + gr.grad, 1e-3, 1e-2, "ln_finalize dgamma")
+    close(o3[2], 1 + (g0 + xr.grad).sum(0), 1e-3, 1e-2, "ln_finalize colsum")
+    assert float((o3[1] - 1).abs().max()) == 0.0
     # strided rows + g_init (final norm on CLS rows)
     N = 5; n_img = 40
     xs = torch.randn(n_img * N, D, generator=g).to(dev)

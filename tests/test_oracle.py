@@ -1,0 +1,153 @@
+"""CPU: pin the oracle (oracle/) against independent implementations that are installed here
+-- the reference holds no tests or golden vectors, so this is what stands
+behind "the oracle restates the reference's arithmetic" -- and against the committed fixtures."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import step_oracle as so, vit_oracle as vo
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_primitives_match_torch_nn():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 17, 192, generator=g, dtype=torch.float64)
+    w, b = torch.randn(192, generator=g, dtype=torch.float64), torch.randn(192, generator=g, dtype=torch.float64)
+    assert torch.allclose(vo.layer_norm(x, w, b), F.layer_norm(x, (192,), w, b, 1e-6), atol=1e-12)
+    assert torch.allclose(vo.gelu(x), F.gelu(x), atol=1e-12)
+
+
+def test_attention_matches_sdpa():
+    p = vo.init_vit("vit_tiny", 64, 0, seed=3, dtype=torch.float64)
+    x = torch.randn(2, 17, 192, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    got = vo.attention(x, p, "blocks.0.attn.", 3)
+    qkv = (x @ p["blocks.0.attn.qkv.weight"].t() + p["blocks.0.attn.qkv.bias"]).reshape(2, 17, 3, 3, 64).permute(2, 0, 3, 1, 4)
+    o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(2, 17, 192)
+    ref = o @ p["blocks.0.attn.proj.weight"].t() + p["blocks.0.attn.proj.bias"]
+    assert torch.allclose(got, ref, atol=1e-10)
+
+
+def test_vit_matches_hf_vitmodel():
+    """Same weights in a locally configured HF ViTModel (no download) give the same tokens."""
+    from transformers import ViTConfig, ViTModel
+    arch, img = "vit_tiny", 64
+    a = vo.ARCHS[arch]
+    cfg = ViTConfig(hidden_size=a["embed_dim"], num_hidden_layers=a["depth"], num_attention_heads=a["num_heads"],
+                    intermediate_size=4 * a["embed_dim"], image_size=img, patch_size=16, layer_norm_eps=1e-6, qkv_bias=True,
+                    hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    hf = ViTModel(cfg, add_pooling_layer=False).eval()
+    p = vo.init_vit(arch, img, 0, seed=0)
+    D = a["embed_dim"]
+    sd = {"embeddings.cls_token": p["cls_token"], "embeddings.position_embeddings": p["pos_embed"],
+          "embeddings.patch_embeddings.projection.weight": p["patch_embed.proj.weight"],
+          "embeddings.patch_embeddings.projection.bias": p["patch_embed.proj.bias"],
+          "layernorm.weight": p["norm.weight"], "layernorm.bias": p["norm.bias"]}
+    for i in range(a["depth"]):        # key names of transformers 5.x ViTModel
+        b, h = f"blocks.{i}.", f"layers.{i}."
+        qw, qb = p[b + "attn.qkv.weight"], p[b + "attn.qkv.bias"]
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            sd[h + f"attention.{nm}.weight"] = qw[j * D:(j + 1) * D]
+            sd[h + f"attention.{nm}.bias"] = qb[j * D:(j + 1) * D]
+        sd[h + "attention.o_proj.weight"] = p[b + "attn.proj.weight"]; sd[h + "attention.o_proj.bias"] = p[b + "attn.proj.bias"]
+        sd[h + "layernorm_before.weight"] = p[b + "norm1.weight"]; sd[h + "layernorm_before.bias"] = p[b + "norm1.bias"]
+        sd[h + "layernorm_after.weight"] = p[b + "norm2.weight"]; sd[h + "layernorm_after.bias"] = p[b + "norm2.bias"]
+        sd[h + "mlp.fc1.weight"] = p[b + "mlp.fc1.weight"]; sd[h + "mlp.fc1.bias"] = p[b + "mlp.fc1.bias"]
+        sd[h + "mlp.fc2.weight"] = p[b + "mlp.fc2.weight"]; sd[h + "mlp.fc2.bias"] = p[b + "mlp.fc2.bias"]
+    have = set(hf.state_dict())
+    sd = {k: v for k, v in sd.items()}
+    assert set(sd) == have, (sorted(set(sd) - have)[:5], sorted(have - set(sd))[:5])
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not [m for m in missing if "pooler" not in m] and not unexpected, (missing, unexpected)
+    x = torch.randn(2, 3, img, img, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = hf(pixel_values=x).last_hidden_state
+        got = vo.vit_features(p, x, arch, return_tokens=True)
+    assert torch.allclose(got, ref, atol=2e-5), float((got - ref).abs().max())
+
+
+def test_dino_head_matches_weight_norm_module():
+    hp = vo.init_dino_head(192, 512, seed=2)
+    mlp = nn.Sequential(nn.Linear(192, 2048), nn.GELU(), nn.Linear(2048, 2048), nn.GELU(), nn.Linear(2048, 256))
+    last = nn.utils.weight_norm(nn.Linear(256, 512, bias=False))
+    with torch.no_grad():
+        for i in (0, 2, 4):
+            mlp[i].weight.copy_(hp[f"mlp.{i}.weight"]); mlp[i].bias.copy_(hp[f"mlp.{i}.bias"])
+        last.weight_g.copy_(hp["last_layer.weight_g"]); last.weight_v.copy_(hp["last_layer.weight_v"])
+    x = torch.randn(5, 192, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        ref = last(F.normalize(mlp(x), dim=-1, p=2))
+    assert torch.allclose(vo.dino_head(hp, x), ref, atol=1e-5)
+
+
+def test_softmax_lsce_matches_reference_formula():
+    """train.py:1046 softmax then timm LabelSmoothingCrossEntropy with the gather patched to
+    target[B,1] (train_instruct.txt:3-7): restated here independently with F.* calls."""
+    z = torch.randn(9, 2, generator=torch.Generator().manual_seed(1))
+    t = torch.randint(0, 2, (9, 1), generator=torch.Generator().manual_seed(2))
+    out = F.softmax(z, dim=1)
+    logp = F.log_softmax(out, dim=-1)
+    ref = (0.9 * (-logp.gather(-1, t).squeeze(1)) + 0.1 * (-logp.mean(-1))).mean()
+    assert torch.allclose(vo.softmax_lsce(z, t, 0.1), ref, atol=1e-7)
+
+
+def test_dino_loss_matches_explicit_pairs():
+    B, V, G, K = 3, 5, 2, 64
+    g = torch.Generator().manual_seed(0)
+    s, t, c = torch.randn(V * B, K, generator=g), torch.randn(G * B, K, generator=g), 0.1 * torch.randn(1, K, generator=g)
+    loss, bsum = vo.dino_loss(s, t, c, V, G, 0.1, 0.04)
+    tp = F.softmax((t - c) / 0.04, -1).view(G, B, K); ls = F.log_softmax(s / 0.1, -1).view(V, B, K)
+    tot = sum(-(tp[iq] * ls[v]).sum(-1).mean() for iq in range(G) for v in range(V) if v != iq) / (G * (V - 1))
+    assert torch.allclose(loss, tot, atol=1e-6) and torch.allclose(bsum[0], t.sum(0))
+
+
+def test_interpolate_pos_encoding_matches_linear_map():
+    """The engine resamples the pos-embed with a fixed matrix; it must equal the bicubic call."""
+    import gipvit.engine as E
+    pos = torch.randn(1, 197, 32, generator=torch.Generator().manual_seed(0))
+    ref = vo.interpolate_pos_encoding(pos, 36, 96, 96)
+    M = E.pos_interp_matrix(14, 96)
+    got = M @ pos[0, 1:]
+    assert torch.allclose(got, ref[0, 1:], atol=1e-5) and torch.equal(ref[0, 0], pos[0, 0])
+
+
+def test_adamw_matches_torch():
+    p0 = {"w": torch.randn(7, 5, generator=torch.Generator().manual_seed(0)), "b.bias": torch.randn(5, generator=torch.Generator().manual_seed(1))}
+    mine = {k: v.clone() for k, v in p0.items()}
+    opt = vo.AdamW(mine, 1e-2, 0.1)
+    ref = [nn.Parameter(v.clone()) for v in p0.values()]
+    topt = torch.optim.AdamW([{"params": [ref[0]], "weight_decay": 0.1}, {"params": [ref[1]], "weight_decay": 0.0}], lr=1e-2)
+    for s in range(3):
+        gs = {k: torch.randn_like(v, generator=None) * 0 + (s + 1) * 0.1 * torch.sign(v) for k, v in p0.items()}
+        for r, g in zip(ref, gs.values()):
+            r.grad = g.clone()
+        topt.step(); opt.step(gs)
+    assert torch.allclose(mine["w"], ref[0].detach(), atol=1e-6) and torch.allclose(mine["b.bias"], ref[1].detach(), atol=1e-6)
+
+
+def test_golden_supervised_c1():
+    """BASELINE config 1 (ViT-T/16, 64x64, supervised head, batch 8) reproduces its fixture."""
+    gold = np.load(os.path.join(GOLD, "supervised_c1.npz"))
+    orc = so.SupervisedOracle(arch="vit_tiny", img_size=64, num_classes=2, seed=0, lr=1e-4, wd=0.05)
+    tiles = vo.synth_tiles(8, 64, seed=1234)
+    tgt = torch.randint(0, 2, (8, 1), generator=torch.Generator().manual_seed(5))
+    loss0, grads0, logits0 = orc.forward_backward(tiles, tgt)
+    assert abs(float(loss0) - float(gold["loss0"])) < 1e-5
+    assert np.allclose(logits0.numpy(), gold["logits0"], atol=1e-5)
+    assert abs(so.grad_norm(grads0) - float(gold["grad_norm0"])) < 1e-4 * float(gold["grad_norm0"])
+    curve = [orc.step(tiles, tgt)["loss"] for _ in range(5)]
+    assert np.allclose(curve, gold["curve"][:5], atol=2e-4)
+
+
+def test_golden_dino_tiny():
+    gold = np.load(os.path.join(GOLD, "dino_tiny.npz"))
+    orc = so.DinoOracle(arch="vit_tiny", img_size=224, out_dim=4096, seed=0)
+    loss, grads, s_out, t_out, bsum = orc.forward_backward(vo.synth_tiles(2, 256, seed=1234))
+    assert abs(float(loss) - float(gold["loss"])) < 1e-4
+    assert np.allclose(s_out.numpy()[:, :64], gold["student"], atol=1e-4)
+    assert np.allclose(grads["head.last_layer.weight_v"].numpy()[:4, :32], gold["g_last"], atol=1e-6, rtol=1e-3)

@@ -23,7 +23,7 @@ struct Shape { const char* name; int M, N, K; bool ta, tb; int epi; bool cf32; }
 
 template <class C, bool TA, bool TB, typename OutT, int EPI>
 float run_cfg(const Shape& sh, GemmP p, int reps, int persistent_mult, int order) {
-    constexpr int WPC = (160 * 1024 / C::LDS) < 2 ? 1 : 2;
+    constexpr int WPC = (160 * 1024 / C::LDS) < 2 ? 1 : ((160 * 1024 / C::LDS) >= 4 && C::THREADS == 256 ? 4 : 2);
     auto kern = lab_kernel<C, TA, TB, OutT, false, EPI, WPC>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     p.tiles_m = (sh.M + C::BM - 1) / C::BM; p.tiles_n = (sh.N + C::BN - 1) / C::BN;
@@ -101,6 +101,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(A, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), nB * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, 4096 * 4)); CK(hipMemset(resid, 0, nC * 4)); CK(hipMemset(aux, 0, nC * 2));
     //            BM   BN  BK WM WN NSTAGE
+    if (only_cfg < 0 || only_cfg == 10) run_all<Cfg<128, 128, 32, 2, 2, 2>>("128x128 k32 2x2 s2 w4", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 11) run_all<Cfg<128, 64, 64, 2, 2, 2>>("128x64 k64 2x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
     if (only_cfg < 0 || only_cfg == 0) run_all<Cfg<128, 128, 32, 2, 2, 4>>("128x128 k32 2x2 s4", shapes, A, B, C, nullptr, bias, aux, resid);
     if (only_cfg < 0 || only_cfg == 1) run_all<Cfg<128, 128, 64, 2, 2, 2>>("128x128 k64 2x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
     if (only_cfg < 0 || only_cfg == 2) run_all<Cfg<128, 128, 64, 2, 2, 3>>("128x128 k64 2x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
