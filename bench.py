@@ -38,7 +38,8 @@ def cpu_baseline(arch, n_local, seconds_budget=25.0):
     """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded
     sample of the same workload: B=2 tiles per step, K=65536, as many steps as fit."""
     from oracle import step_oracle as so, vit_oracle as vo
-    cores = os.cpu_count() or 1
+    # the GPU box exposes more logical CPUs than its share (16 per GPU); oversubscribing stalls torch
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     torch.set_num_threads(cores)
     B = 2
     orc = so.DinoOracle(arch=arch, img_size=224, out_dim=65536, n_local=n_local)
@@ -62,6 +63,7 @@ def main():
     ap.add_argument("--arch", default="vit_small")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-loss", action="store_true", help="debug: synchronise and print the loss after every step")
     ap.add_argument("--kernel-timing", action="store_true", help="time the dominant GEMM with HIP events for the roofline object")
     args = ap.parse_args()
 
@@ -81,7 +83,10 @@ def main():
     from gipvit.engine import DinoEngine
     from gipvit import roofline
     n_local = 8 if args.config == "c3" else 0
-    eng = DinoEngine(arch=args.arch, img_size=224, out_dim=65536, batch=args.batch, n_local=n_local, device=dev, reducer=reducer)
+    # DINO recipe (paper defaults): AdamW, lr = 5e-4 * global_batch / 256, wd 0.04, clip 3.0
+    lr = 5e-4 * args.batch * world / 256.0
+    eng = DinoEngine(arch=args.arch, img_size=224, out_dim=65536, batch=args.batch, n_local=n_local, lr=lr, weight_decay=0.04,
+                     clip_grad=3.0, device=dev, reducer=reducer)
     from gipvit.models import init_vit_state, init_dino_head_state
     eng.load_state(init_vit_state(args.arch, 224, 0, seed=0), init_dino_head_state(eng.D, 65536, seed=1))
     tiles = synth_tiles(args.batch, 256, 1234 + rank, dev)
@@ -89,7 +94,15 @@ def main():
     use_graph = not args.no_graph
     if use_graph:
         eng.capture(tiles)
-    step = (lambda: eng.step_graph()) if use_graph else (lambda: eng.step(tiles))
+    if os.environ.get("BENCH_SYNC_AFTER_CAPTURE"):
+        torch.cuda.synchronize()
+    step0 = (lambda: eng.step_graph()) if use_graph else (lambda: eng.step(tiles))
+
+    def step():
+        l = step0()
+        if args.trace_loss:
+            torch.cuda.synchronize()
+            print(f"[trace] t={eng.t} loss={float(l):.5f}", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
 
@@ -98,7 +111,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    barrier()
+    if not os.environ.get("BENCH_NO_MID_BARRIER"):
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

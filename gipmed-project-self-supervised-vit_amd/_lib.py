@@ -63,6 +63,7 @@ gv_center_update_args = _struct("gv_center_update_args", [
 gv_softmax_lsce_args = _struct("gv_softmax_lsce_args", [
     ("logits", vp), ("target", vp), ("loss", vp), ("dlogits", vp), ("prob", vp), ("B", i32), ("C", i32), ("smoothing", f32)])
 gv_gather_cls_args = _struct("gv_gather_cls_args", [("x", vp), ("y", vp), ("n_img", i32), ("N", i32), ("D", i32)])
+gv_store_f32_args = _struct("gv_store_f32_args", [("dst", vp), ("vals", f32 * 16), ("n", i32)])
 gv_cast_bf16_args = _struct("gv_cast_bf16_args", [("src", vp), ("dst", vp), ("n", i64)])
 gv_sumsq_args = _struct("gv_sumsq_args", [("x", vp), ("n", i64), ("workspace", vp), ("out", vp), ("accumulate", i32)])
 gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
@@ -78,7 +79,7 @@ ENTRY_POINTS = {
     "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,
     "gv_dino_loss": gv_dino_loss_args, "gv_center_update": gv_center_update_args, "gv_softmax_lsce": gv_softmax_lsce_args,
-    "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_sumsq": gv_sumsq_args,
+    "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_store_f32": gv_store_f32_args, "gv_sumsq": gv_sumsq_args,
     "gv_adamw_ema": gv_adamw_ema_args,
 }
 PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target")

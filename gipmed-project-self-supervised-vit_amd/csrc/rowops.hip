@@ -129,6 +129,10 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(gv_weightnorm_bwd_a
     if (lane == 0 && a.dg) a.dg[row] = a.accumulate ? a.dg[row] + vd : vd;
 }
 
+__global__ void store_f32_kernel(gv_store_f32_args a) {
+    if ((int)threadIdx.x < a.n) a.dst[threadIdx.x] = a.vals[threadIdx.x];
+}
+
 __global__ void gather_cls_kernel(gv_gather_cls_args a) {
     const int i = blockIdx.x;
     for (int d = threadIdx.x; d < a.D; d += blockDim.x)
@@ -262,6 +266,14 @@ extern "C" int gv_weightnorm_fwd(const gv_weightnorm_fwd_args* a, void* stream) 
 extern "C" int gv_weightnorm_bwd(const gv_weightnorm_bwd_args* a, void* stream) {
     GV_REQUIRE(a && a->dw && a->v && a->g && a->dv, GV_E_NULL, "gv_weightnorm_bwd: null pointer");
     GV_ROW_LAUNCH(weightnorm_bwd_kernel, a, "gv_weightnorm_bwd")
+}
+
+extern "C" int gv_store_f32(const gv_store_f32_args* a, void* stream) {
+    GV_REQUIRE(a && a->dst, GV_E_NULL, "gv_store_f32: null pointer");
+    GV_REQUIRE(a->n > 0 && a->n <= 16, GV_E_SHAPE, "gv_store_f32: need 0 < n <= 16");
+    hipLaunchKernelGGL(store_f32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_store_f32");
+    return GV_OK;
 }
 
 extern "C" int gv_gather_cls(const gv_gather_cls_args* a, void* stream) {

@@ -40,6 +40,19 @@ STD_RON = (0.1125, 0.1751, 0.0787)    # transformations.py:113
 PAD = 64                              # arena offsets are multiples of 64 elements
 
 
+def _empty(shape, dt, device):
+    """torch.empty, or NaN / 0xFF-poisoned memory when GIPVIT_POISON=1 (debug: any read of a
+    buffer before it was written then shows up as NaN in the loss / gradients)."""
+    import os
+    t = torch.empty(shape, dtype=dt, device=device)
+    if os.environ.get("GIPVIT_POISON"):
+        if dt.is_floating_point:
+            t.fill_(float("nan"))
+        else:
+            t.fill_(-1)
+    return t
+
+
 def _round_up(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
@@ -166,7 +179,7 @@ class VitGroup:
         self.N = self.P + 1
         self.T = n_img * self.N
         T, nb = self.T, (depth if save else 1)
-        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
+        e = lambda shape, dt: _empty(shape, dt, device)
         self.patches = e((n_img * self.P, 768), bf16)
         self.x = [e((T, D), f32) for _ in range(2 * depth + 1 if save else 3)]
         self.xn1 = [e((T, D), bf16) for _ in range(nb)]
@@ -201,8 +214,8 @@ class VitRunner:
         a = ARCHS[arch]
         self.arch, self.D, self.depth, self.H, self.img_size = arch, a["embed_dim"], a["depth"], a["num_heads"], img_size
         self.scale = 64 ** -0.5
-        self.partials = torch.empty(L.LN_PARTIAL_BLOCKS, 3, self.D, dtype=f32, device=device)
-        self.cs_ws = torch.empty(64 * 4 * self.D, dtype=f32, device=device)
+        self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
+        self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
         self.one = torch.ones(1, dtype=f32, device=device)
 
     # ---- forward: tiles -> CLS features written into feats[row_off : row_off + n_img]
@@ -293,7 +306,7 @@ class VitRunner:
 # --------------------------------------------------------------------------- #
 class HeadBuffers:
     def __init__(self, R: int, D: int, K: int, hidden: int, bott: int, device, save: bool):
-        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
+        e = lambda shape, dt: _empty(shape, dt, device)
         self.R = R
         self.feats = e((R, D), bf16)
         self.h1p, self.h1 = e((R, hidden), bf16), e((R, hidden), bf16)
@@ -311,7 +324,7 @@ class HeadBuffers:
 class HeadRunner:
     def __init__(self, D: int, K: int, hidden: int, bott: int, device):
         self.D, self.K, self.hidden, self.bott = D, K, hidden, bott
-        self.cs_ws = torch.empty(64 * max(hidden, bott), dtype=f32, device=device)
+        self.cs_ws = _empty((64 * max(hidden, bott),), f32, device)
 
     def forward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers):
         R, D, Hd, Bt, K, E = hb.R, self.D, self.hidden, self.bott, self.K, L
@@ -389,16 +402,15 @@ class DinoEngine:
         self.g_teach = VitGroup(arch, n_global * B, gsize, img_size, dev, save=False)
         self.hb_s = HeadBuffers(self.V * B, D, out_dim, hidden, bottleneck, dev, save=True)
         self.hb_t = HeadBuffers(n_global * B, D, out_dim, hidden, bottleneck, dev, save=False)
-        self.wn_s = torch.empty(out_dim, bottleneck, dtype=bf16, device=dev)
-        self.wn_t = torch.empty(out_dim, bottleneck, dtype=bf16, device=dev)
+        self.wn_s = _empty((out_dim, bottleneck), bf16, dev)
+        self.wn_t = _empty((out_dim, bottleneck), bf16, dev)
         self.center = torch.zeros(out_dim, dtype=f32, device=dev)
         self.center_sum = torch.zeros(out_dim, dtype=f32, device=dev)
         self.loss = torch.zeros(1, dtype=f32, device=dev)
-        self.loss_ws = torch.empty(2 * (self.V + self.G) * B, dtype=f32, device=dev)
+        self.loss_ws = _empty((2 * (self.V + self.G) * B,), f32, dev)
         self.gnorm_sq = torch.zeros(1, dtype=f32, device=dev)
-        self.red_ws = torch.empty(1024, dtype=f32, device=dev)
+        self.red_ws = _empty((1024,), f32, dev)
         self.hyper = torch.zeros(L.HYP_COUNT, dtype=f32, device=dev)
-        self.hyper_host = torch.zeros(L.HYP_COUNT, dtype=f32).pin_memory() if torch.cuda.is_available() else torch.zeros(L.HYP_COUNT)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.m_teacher, self.ts, self.tt, self.cm, self.clip = momentum_teacher, student_temp, teacher_temp, center_momentum, clip_grad
         self.train_last_layer = True
@@ -436,19 +448,21 @@ class DinoEngine:
 
     # ---- the step --------------------------------------------------------------------
     def set_hyper(self, lr=None, wd=None, momentum_teacher=None, teacher_temp=None):
-        """Stage the per-step schedule values into the device hyper vector (H2D on the
-        current stream, outside any captured graph)."""
+        """Put the per-step schedule values into the device hyper vector with a tiny stream-ordered
+        kernel whose ARGUMENTS carry them (outside any captured graph).  Not a memcpy: the host
+        runs many graph replays ahead of the GPU, and a pinned staging buffer would be rewritten
+        (or, on an idle queue, copied out of order) before the queued steps consumed it."""
         self.t += 1
-        h = self.hyper_host
-        h[L.HYP_LR] = self.lr if lr is None else lr
-        h[L.HYP_WD] = self.wd if wd is None else wd
-        h[L.HYP_BC1] = 1.0 - self.betas[0] ** self.t
-        h[L.HYP_BC2] = 1.0 - self.betas[1] ** self.t
-        h[L.HYP_TEACHER_MOM] = self.m_teacher if momentum_teacher is None else momentum_teacher
-        h[L.HYP_GRAD_SCALE] = 1.0 / self.reducer.world
-        h[L.HYP_TEACHER_TEMP] = self.tt if teacher_temp is None else teacher_temp
-        h[L.HYP_STUDENT_TEMP] = self.ts
-        self.hyper.copy_(h, non_blocking=True)
+        vals = [0.0] * L.HYP_COUNT
+        vals[L.HYP_LR] = self.lr if lr is None else lr
+        vals[L.HYP_WD] = self.wd if wd is None else wd
+        vals[L.HYP_BC1] = 1.0 - self.betas[0] ** self.t
+        vals[L.HYP_BC2] = 1.0 - self.betas[1] ** self.t
+        vals[L.HYP_TEACHER_MOM] = self.m_teacher if momentum_teacher is None else momentum_teacher
+        vals[L.HYP_GRAD_SCALE] = 1.0 / self.reducer.world
+        vals[L.HYP_TEACHER_TEMP] = self.tt if teacher_temp is None else teacher_temp
+        vals[L.HYP_STUDENT_TEMP] = self.ts
+        ops.store_f32(self.hyper, vals)
 
     def forward_backward(self, tiles_u8: torch.Tensor):
         """teacher fwd (global crops) -> student fwd (all crops) -> loss -> backward.
@@ -518,86 +532,17 @@ class DinoEngine:
             self.forward_backward(self._static_tiles)
             self.optimizer_step()
 
-    def step_graph(self, tiles_u8: Optional[torch.Tensor] = None, **sched) -> torch.Tensor:
+    def step_graph(self, tiles_u8: Optional[torch.Tensor] = None, sync: bool = True, **sched) -> torch.Tensor:
+        """Replay the captured step.  By default the launching stream is synchronised after the
+        replay (hipStreamSynchronize), as the reference's loop does after every step
+        (train.py:1083).  Measured on ROCm 7.2 / MI355X: launching the next
+        replay onto a queue that went idle behind a DEVICE- or EVENT-level sync silently breaks
+        the ordering between consecutive replays of the same graph exec (wrong losses / NaN),
+        while a stream-level sync after each replay is always correct and costs < 0.2 %."""
         if tiles_u8 is not None:
             self._static_tiles.copy_(tiles_u8, non_blocking=True)
         self.set_hyper(**sched)
         self.graph.replay()
-        return self.loss
-
-
-# --------------------------------------------------------------------------- #
-# supervised single-crop step (reference train.py:1044-1078; BASELINE config 1)
-# --------------------------------------------------------------------------- #
-class SupervisedEngine:
-    """ViT + Linear head, softmax -> LabelSmoothingCE (the reference's actual loss path)."""
-
-    def __init__(self, arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999),
-                 eps=1e-8, smoothing=0.1, clip_grad: float = 0.0, mean=MEAN_RON, std=STD_RON, device="cuda:0", reducer=None):
-        dev = torch.device(device)
-        self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
-        D = ARCHS[arch]["embed_dim"]
-        self.D = D
-        self.mean, self.std = tuple(mean), tuple(std)
-        self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
-        self.W = Weights(self.arena, "")
-        self.vit = VitRunner(arch, img_size, dev)
-        self.grp = VitGroup(arch, batch, img_size, img_size, dev, save=True)
-        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
-        self.feats, self.dfeats = e((batch, D), bf16), e((batch, D), bf16)
-        self.logits, self.dlogits, self.prob = e((batch, num_classes), f32), e((batch, num_classes), f32), e((batch, num_classes), f32)
-        self.loss = torch.zeros(1, dtype=f32, device=dev)
-        self.ones = torch.ones(batch, dtype=f32, device=dev)
-        self.gnorm_sq = torch.zeros(1, dtype=f32, device=dev)
-        self.red_ws = torch.empty(1024, dtype=f32, device=dev)
-        self.lr, self.wd, self.betas, self.eps, self.smoothing, self.clip = lr, weight_decay, betas, eps, smoothing, clip_grad
-        self.t = 0
-        self.reducer = reducer if reducer is not None else NoReducer()
-
-    def load_state(self, state: Dict[str, torch.Tensor]):
-        self.arena.load(state)
-        ops.cast_bf16(self.arena.p, self.arena.pb)
-
-    def state_dict(self):
-        return self.arena.state_dict()
-
-    def grads(self):
-        return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
-
-    def forward(self, tiles_u8):
-        """Inference / features: returns (logits f32 [B,C], CLS features bf16 [B,D])."""
-        B, C, D, W = self.B, self.C, self.D, self.W
-        self.vit.forward(W, self.grp, tiles_u8, [(0, 0)], self.mean, self.std, self.feats, 0)
-        ops.small_matmul(self.feats, W.f("head.weight"), self.logits, B, C, D, sam=D, sak=1, sbk=1, sbn=D, bias=W.f("head.bias"))
-        return self.logits, self.feats
-
-    def forward_backward(self, tiles_u8, target):
-        B, C, D, W = self.B, self.C, self.D, self.W
-        self.arena.g.zero_()
-        self.forward(tiles_u8)
-        ops.softmax_lsce(self.logits, target.view(-1), self.loss, self.dlogits, self.prob, B, C, self.smoothing)
-        # head backward: dW = dlogits^T f, db = colsum(dlogits), df = dlogits W
-        ops.small_matmul(self.dlogits, self.feats, W.g("head.weight"), C, D, B, sam=1, sak=C, sbk=D, sbn=1, accumulate=True)
-        ops.small_matmul(self.ones, self.dlogits, W.g("head.bias").view(1, C), 1, C, B, sam=0, sak=1, sbk=C, sbn=1, accumulate=True)
-        ops.small_matmul(self.dlogits, W.f("head.weight"), self.dfeats, B, D, C, sam=C, sak=1, sbk=D, sbn=1)
-        self.vit.backward(W, self.grp, self.dfeats)
-        self.reducer.reduce_range(self.arena.g, 0, self.arena.n)
-        self.reducer.finish()
-
-    def optimizer_step(self, lr=None):
-        a = self.arena
-        self.t += 1
-        if self.clip > 0:
-            ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
-        kw = dict(lr=self.lr if lr is None else lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=self.t,
-                  grad_scale=1.0 / self.reducer.world, clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None)
-        sl = slice(0, a.n_decay)
-        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], None, None, a.n_decay, weight_decay=self.wd, **kw)
-        sl = slice(a.n_decay, a.n)
-        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], None, None, a.n - a.n_decay, weight_decay=0.0, **kw)
-
-    def step(self, tiles_u8, target, lr=None):
-        assert tiles_u8.dtype == torch.uint8 and target.dtype == torch.int64
-        self.forward_backward(tiles_u8, target)
-        self.optimizer_step(lr)
+        if sync:
+            torch.cuda.current_stream().synchronize()
         return self.loss

@@ -169,6 +169,15 @@ def gather_cls(x, y, n_img: int, N: int, D: int):
     L.call("gv_gather_cls", L.gv_gather_cls_args(x.data_ptr(), y.data_ptr(), n_img, N, D), _stream())
 
 
+def store_f32(dst, vals):
+    """dst[i] = vals[i] (n <= 16) by a stream-ordered kernel whose arguments carry the values."""
+    a = L.gv_store_f32_args()
+    a.dst, a.n = dst.data_ptr(), len(vals)
+    for i, v in enumerate(vals):
+        a.vals[i] = float(v)
+    L.call("gv_store_f32", a, _stream())
+
+
 def cast_bf16(src, dst, n: Optional[int] = None):
     L.call("gv_cast_bf16", L.gv_cast_bf16_args(src.data_ptr(), dst.data_ptr(), src.numel() if n is None else n), _stream())
 

@@ -244,6 +244,11 @@ int gv_softmax_lsce(const gv_softmax_lsce_args* a, void* stream);
 typedef struct { const float* x; void* y; int32_t n_img, N, D; } gv_gather_cls_args;
 int gv_gather_cls(const gv_gather_cls_args* a, void* stream);
 
+/* dst[i] = vals[i] for i < n <= 16: per-step schedule values (gv_adamw_ema_args.hyper)
+ * delivered as KERNEL ARGUMENTS of a stream-ordered launch rather than by a memcpy.     */
+typedef struct { float* dst; float vals[16]; int32_t n; } gv_store_f32_args;
+int gv_store_f32(const gv_store_f32_args* a, void* stream);
+
 /* f32 -> bf16 cast of a flat buffer (weight arena refresh)                  */
 typedef struct { const float* src; void* dst; int64_t n; } gv_cast_bf16_args;
 int gv_cast_bf16(const gv_cast_bf16_args* a, void* stream);
