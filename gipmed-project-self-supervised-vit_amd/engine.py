@@ -533,16 +533,106 @@ class DinoEngine:
             self.optimizer_step()
 
     def step_graph(self, tiles_u8: Optional[torch.Tensor] = None, sync: bool = True, **sched) -> torch.Tensor:
-        """Replay the captured step.  By default the launching stream is synchronised after the
-        replay (hipStreamSynchronize), as the reference's loop does after every step
-        (train.py:1083).  Measured on ROCm 7.2 / MI355X: launching the next
-        replay onto a queue that went idle behind a DEVICE- or EVENT-level sync silently breaks
-        the ordering between consecutive replays of the same graph exec (wrong losses / NaN),
-        while a stream-level sync after each replay is always correct and costs < 0.2 %."""
+        """Replay the captured step, then (default) ``torch.cuda.synchronize()`` -- the same
+        device-wide sync the reference's loop issues after every step (train.py:1083).
+
+        This is a correctness requirement on ROCm 7.2 / MI355X, not a convenience (measurements
+        in DESIGN.md section 7, tools/replay_cfg.py): work launched by hipGraphLaunch is not
+        reliably covered by STREAM- or EVENT-level ordering -- a stream sync can return while the
+        replay's tail kernels still run (a loss read then sees a partial atomic sum), and replays
+        queued back-to-back behind a device sync overlap (optimizer of step k racing the
+        gradient zeroing of step k+1: wrong losses, NaN).  A device-wide sync after each replay
+        has been exact in every experiment and costs < 0.2 % at 25 ms / step."""
         if tiles_u8 is not None:
             self._static_tiles.copy_(tiles_u8, non_blocking=True)
         self.set_hyper(**sched)
         self.graph.replay()
         if sync:
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.synchronize()
+        return self.loss
+
+
+# --------------------------------------------------------------------------- #
+# supervised single-crop step (reference train.py:1044-1078; BASELINE config 1)
+# --------------------------------------------------------------------------- #
+class SupervisedEngine:
+    """ViT + Linear head, softmax -> LabelSmoothingCE (the reference's actual loss path)."""
+
+    def __init__(self, arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999),
+                 eps=1e-8, smoothing=0.1, clip_grad: float = 0.0, mean=MEAN_RON, std=STD_RON, device="cuda:0", reducer=None,
+                 opt: str = "adamw", momentum: float = 0.9, train_backbone: bool = True):
+        dev = torch.device(device)
+        self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
+        D = ARCHS[arch]["embed_dim"]
+        self.D = D
+        self.mean, self.std = tuple(mean), tuple(std)
+        self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
+        self.W = Weights(self.arena, "")
+        self.vit = VitRunner(arch, img_size, dev)
+        self.grp = VitGroup(arch, batch, img_size, img_size, dev, save=True)
+        e = lambda shape, dt: _empty(shape, dt, dev)
+        self.feats, self.dfeats = e((batch, D), bf16), e((batch, D), bf16)
+        self.logits, self.dlogits, self.prob = e((batch, num_classes), f32), e((batch, num_classes), f32), e((batch, num_classes), f32)
+        self.loss = torch.zeros(1, dtype=f32, device=dev)
+        self.ones = torch.ones(batch, dtype=f32, device=dev)
+        self.gnorm_sq = torch.zeros(1, dtype=f32, device=dev)
+        self.red_ws = _empty((1024,), f32, dev)
+        self.lr, self.wd, self.betas, self.eps, self.smoothing, self.clip = lr, weight_decay, betas, eps, smoothing, clip_grad
+        self.t = 0
+        self.reducer = reducer if reducer is not None else NoReducer()
+        if opt not in ("adamw", "adam", "sgd"):
+            raise ValueError(f"--opt {opt}: this build fuses adamw / adam / sgd (nesterov) only")
+        self.opt_mode = {"adamw": 0, "adam": 1, "sgd": 2}[opt]
+        if opt == "sgd":
+            self.betas = (momentum, betas[1])
+        self.train_backbone = train_backbone      # False = --no-grad head-only fine-tune (train.py:497-503)
+
+    def load_state(self, state: Dict[str, torch.Tensor]):
+        self.arena.load(state)
+        ops.cast_bf16(self.arena.p, self.arena.pb)
+
+    def state_dict(self):
+        return self.arena.state_dict()
+
+    def grads(self):
+        return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
+
+    def forward(self, tiles_u8):
+        """Inference / features: returns (logits f32 [B,C], CLS features bf16 [B,D])."""
+        B, C, D, W = self.B, self.C, self.D, self.W
+        self.vit.forward(W, self.grp, tiles_u8, [(0, 0)], self.mean, self.std, self.feats, 0)
+        ops.small_matmul(self.feats, W.f("head.weight"), self.logits, B, C, D, sam=D, sak=1, sbk=1, sbn=D, bias=W.f("head.bias"))
+        return self.logits, self.feats
+
+    def forward_backward(self, tiles_u8, target):
+        B, C, D, W = self.B, self.C, self.D, self.W
+        self.arena.g.zero_()
+        self.forward(tiles_u8)
+        ops.softmax_lsce(self.logits, target.view(-1), self.loss, self.dlogits, self.prob, B, C, self.smoothing)
+        # head backward: dW = dlogits^T f, db = colsum(dlogits), df = dlogits W
+        ops.small_matmul(self.dlogits, self.feats, W.g("head.weight"), C, D, B, sam=1, sak=C, sbk=D, sbn=1, accumulate=True)
+        ops.small_matmul(self.ones, self.dlogits, W.g("head.bias").view(1, C), 1, C, B, sam=0, sak=1, sbk=C, sbn=1, accumulate=True)
+        ops.small_matmul(self.dlogits, W.f("head.weight"), self.dfeats, B, D, C, sam=C, sak=1, sbk=D, sbn=1)
+        if self.train_backbone:
+            self.vit.backward(W, self.grp, self.dfeats)
+        self.reducer.reduce_range(self.arena.g, 0, self.arena.n)
+        self.reducer.finish()
+
+    def optimizer_step(self, lr=None):
+        a = self.arena
+        self.t += 1
+        if self.clip > 0:
+            ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
+        kw = dict(lr=self.lr if lr is None else lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=self.t,
+                  grad_scale=1.0 / self.reducer.world, clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None,
+                  mode=self.opt_mode)
+        sl = slice(0, a.n_decay)
+        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], None, None, a.n_decay, weight_decay=self.wd, **kw)
+        sl = slice(a.n_decay, a.n)
+        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], None, None, a.n - a.n_decay, weight_decay=0.0, **kw)
+
+    def step(self, tiles_u8, target, lr=None):
+        assert tiles_u8.dtype == torch.uint8 and target.dtype == torch.int64
+        self.forward_backward(tiles_u8, target)
+        self.optimizer_step(lr)
         return self.loss

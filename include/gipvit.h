@@ -275,6 +275,11 @@ typedef struct {
      * [GV_HYP_LR, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
      *  GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP] */
     const float* hyper;
+    /* 0 = AdamW (decoupled decay, torch.optim.AdamW); 1 = Adam with L2 decay folded into the
+     * gradient (timm --opt adam, the documented runs: train_instruct.txt:23); 2 = SGD with
+     * Nesterov momentum beta1 and L2 decay (timm --opt sgd, the reference default, train.py:161);
+     * `m` is the momentum buffer, `v` is unused in mode 2.                                   */
+    int32_t mode;
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
 

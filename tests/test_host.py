@@ -117,3 +117,70 @@ def test_reducer_world_size_2_gloo():
         assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)   # (1 + 2) x
         assert torch.equal(c, torch.full((16,), 3.0))
         assert shard == (32 * rank, 32 * rank + 32)
+
+
+def test_train_cli_keeps_reference_surface(tmp_path):
+    """Every flag of the reference trainer parses (documented command lines of
+    train_instruct.txt:16-34 included), YAML -c defaults work, and without a GPU the driver
+    refuses to run instead of falling back to a CPU path."""
+    import yaml
+    sys.path.insert(0, ROOT)
+    import train
+    from gipvit.cli_spec import REFERENCE_FLAGS
+    assert len(REFERENCE_FLAGS) == 148
+    cmd = ("--model vit_small_patch16_224 --dataset TCGA --target Her2 --num-classes 2 --batch-size 256 --epochs 500 --workers 2 "
+           "--opt adam --lr-base 0.001 --sched cosine --warmup-epochs 20 --supervised --log-wandb --experiment e --subexperiment s").split()
+    args, text = train.parse_args(cmd)
+    assert args.model == "vit_small_patch16_224" and args.batch_size == 256 and args.lr_base == 0.001 and args.supervised
+    assert args.smoothing == 0.1 and args.opt == "adam" and args.test_fold == 1 and args.transform_type == "rvf"
+    cfg = tmp_path / "c.yaml"
+    cfg.write_text(yaml.safe_dump({"epochs": 7, "batch_size": 32}))
+    args, _ = train.parse_args(["-c", str(cfg), "--model", "vit_tiny", "--epochs", "9"])
+    assert args.batch_size == 32 and args.epochs == 9
+    if not torch.cuda.is_available():
+        with pytest.raises(SystemExit, match="MI355X is required"):
+            train.main(["--model", "vit_tiny", "--dataset", "synthetic"])
+
+
+def test_transformations_hook_and_tile_files(tmp_path):
+    import numpy as np
+    from gipvit import transformations as T, data as D
+    t = T.define_transformations("rvf", True, 256, seed=0)
+    a = (np.arange(256 * 256 * 3) % 251).astype(np.uint8).reshape(256, 256, 3)
+    out = t(a)
+    assert out.shape == (256, 256, 3) and out.dtype == np.uint8 and sorted(out.ravel()) == sorted(a.ravel())
+    assert t.mean == (0.8998, 0.8253, 0.9357) and T.define_transformations("none", False, 256, norm_type="Imagenet").std == (0.229, 0.224, 0.225)
+    hook = lambda img: np.asarray(img)[::-1]
+    assert T.define_transformations(hook, True, 256) is hook          # non-string = the user's transform (transformations.py:199-200)
+    with pytest.raises(NotImplementedError):
+        T.define_transformations("pcbnfrsc", True, 256)
+    # reference raw tile format (datasets.py:452-466): "dtype w h c\\n" + bytes
+    os.makedirs(tmp_path / "slideA"); os.makedirs(tmp_path / "slideB")
+    for s, n in (("slideA", 3), ("slideB", 2)):
+        for i in range(n):
+            D.write_tile_file(str(tmp_path / s / f"tile_{i}.data"), (a + i).astype(np.uint8))
+    (tmp_path / "labels.csv").write_text("slide,label\nslideA,1\nslideB,0\n")
+    assert np.array_equal(D.read_tile_file(str(tmp_path / "slideA" / "tile_2.data")), (a + 2).astype(np.uint8))
+    src = D.TileFolder(str(tmp_path), batch=2, transform=None, seed=0)
+    batches = list(src)
+    assert len(batches) == 2 and batches[0]["Data"].shape == (2, 256, 256, 3) and batches[0]["Data"].dtype == torch.uint8
+    assert batches[0]["Target"].shape == (2, 1) and batches[0]["Target"].dtype == torch.int64
+
+
+def test_lr_schedule_and_checkpoint_saver(tmp_path):
+    from gipvit import sched as S
+    from gipvit.checkpoint import CheckpointSaver, load_checkpoint_file
+    assert abs(S.scaled_lr(None, 0.1, 128, 2) - 0.1) < 1e-12                      # linear: 256/256
+    assert abs(S.scaled_lr(None, 0.001, 256, 4, opt="adam") - 0.002) < 1e-12     # sqrt for ada*
+    sc = S.LrSchedule(1.0, "cosine", epochs=10, warmup_epochs=2, warmup_lr=0.0, min_lr=0.0)
+    assert sc.at(0) == 0.0 and sc.at(1) == 0.5 and abs(sc.at(5) - 0.5) < 1e-12 and sc.at(10) < 1e-12
+    assert S.cosine_between(0.996, 1.0, 0, 100) == 0.996 and abs(S.cosine_between(0.996, 1.0, 99, 100) - 1.0) < 1e-12
+    sv = CheckpointSaver(str(tmp_path), "vit_tiny", {"lr": 0.1, "obj": object()}, decreasing=True, max_history=2)
+    sd = {"w": torch.ones(3)}
+    for ep, m in enumerate((3.0, 1.0, 2.0)):
+        best, bep = sv.save_checkpoint(ep, sd, {"exp_avg": torch.zeros(3), "step": ep}, metric=m)
+    assert (best, bep) == (1.0, 1)
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["checkpoint-1.pth.tar", "checkpoint-2.pth.tar", "last.pth.tar", "model_best.pth.tar"]
+    ck = load_checkpoint_file(str(tmp_path / "model_best.pth.tar"))          # weights_only loader
+    assert ck["epoch"] == 1 and ck["version"] == 2 and ck["arch"] == "vit_tiny" and ck["args"] == {"lr": 0.1} and ck["metric"] == 1.0

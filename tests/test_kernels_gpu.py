@@ -369,3 +369,13 @@ def test_adamw_ema(dev):
                 clip_norm=3.0, gnorm_sq=gn)
     c = 3.0 / (math.sqrt(float(gn)) + 1e-6)
     close(m, 0.1 * grad * c, 1e-4, 1e-7, "clipped m")
+    # mode 1: Adam with L2 decay (timm --opt adam); mode 2: SGD Nesterov (timm --opt sgd)
+    for mode, mk in ((1, lambda q: torch.optim.Adam([q], lr=1e-3, weight_decay=0.01)),
+                     (2, lambda q: torch.optim.SGD([q], lr=1e-2, momentum=0.9, nesterov=True, weight_decay=0.01))):
+        pr = p0.clone().requires_grad_(True); opt = mk(pr)
+        p3 = p0.clone(); m.zero_(); v.zero_()
+        for step in (1, 2, 3):
+            pr.grad = grad.clone() * step; opt.step()
+            o.adamw_ema(p3, grad * step, m, v, None, None, None, n, lr=1e-3 if mode == 1 else 1e-2, beta1=0.9, beta2=0.999, eps=1e-8,
+                        weight_decay=0.01, step=step, mode=mode)
+        close(p3, pr.detach(), 1e-5, 1e-6, f"optimizer mode {mode}")
