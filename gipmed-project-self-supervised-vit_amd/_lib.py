@@ -39,7 +39,7 @@ gv_colsum_args = _struct("gv_colsum_args", [
 gv_linear_args = _struct("gv_linear_args", [
     ("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldb", i64), ("ldc", i64),
     ("trans_a", i32), ("trans_b", i32), ("c_is_f32", i32), ("epilogue", i32), ("bias", vp),
-    ("resid", vp), ("ldr", i64), ("aux_in", vp), ("ld_aux", i64), ("aux_out", vp), ("pos", vp), ("P", i32), ("alpha", f32)])
+    ("resid", vp), ("ldr", i64), ("aux_in", vp), ("ld_aux", i64), ("aux_out", vp), ("pos", vp), ("P", i32), ("alpha", f32), ("colsum_a", vp)])
 gv_attention_fwd_args = _struct("gv_attention_fwd_args", [
     ("qkv", vp), ("o", vp), ("lse", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32)])
 gv_attention_bwd_args = _struct("gv_attention_bwd_args", [

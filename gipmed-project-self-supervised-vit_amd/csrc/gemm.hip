@@ -102,6 +102,8 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     p.tiles_m = (a->M + BM - 1) / BM; p.tiles_n = (a->N + BN - 1) / BN;
     p.ksplit = 1; p.k_per_split = ((a->K + BK - 1) / BK) * BK;
     p.order = 0;
+    p.colsum_a = a->colsum_a;
+    if (a->colsum_a) GV_REQUIRE(ta, GV_E_UNSUPPORTED, "gv_linear: colsum_a needs trans_a (it sums the dW product's A operand)");
     hipStream_t s = (hipStream_t)stream;
 
     // Split K when the output grid alone cannot fill 256 CUs (dW: reduction over tens of

@@ -17,6 +17,7 @@ struct GemmP {
     const float* pos; int P;
     float alpha;
     int tiles_m, tiles_n, ksplit, k_per_split;
+    float* colsum_a;   // TA only: += column sums of A (bias gradient), computed as MFMAs against ones
     int order;   // 0: flat m-major items; 1: per-XCD M-panel ranges walked n-major (L2 reuse of A)
 };
 
@@ -210,13 +211,13 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         // ---- the LDS-DMA ring runs PD k-steps ahead of the MFMAs
         int l_k = 0, l_stage = 0;
         auto issue = [&]() {
-            if (l_k < it.nt) {
+            if (l_k < it.nt && !(g.epi & (1 << 21))) {
                 GV_LDS char* st = smem + l_stage * C::STAGE;
                 const int k0 = it.kbeg + l_k * BK;
                 srcA.issue(g.lda, k0, it.kend, st, wave);
                 srcB.issue(g.ldb, k0, it.kend, st + C::A_BYTES, wave);
-                ++l_k;
             }
+            ++l_k;
             l_stage = (l_stage + 1 == NSTAGE) ? 0 : l_stage + 1;
         };
 #pragma unroll
@@ -273,6 +274,15 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // bias gradient fused into the dW product: D[n][m] += ones[n][k] A[m][k] gives every row n the
+        // column sum of A over this item's k range; one extra MFMA per A fragment, no VALU, and dY
+        // is not read a second time.  Done by the wn == 0 waves of the n-tile-0 workgroups.
+        const bool do_colsum = TA && g.colsum_a != nullptr && it.n0 == 0 && wn == 0;
+        f32x4 csum[FM];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16x8 ones = bf16x8{(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+
         int c_stage = 0;
         for (int t = 0; t < it.nt; ++t) {
             // this step's pieces (mine) landed: everything but the younger in-flight steps
@@ -290,6 +300,15 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             // tr reads); the MFMAs then run back-to-back behind the compiler's counted lgkmcnt(N)
             // instead of exposing the LDS latency once per small read group.
             bf16x8 fa[C::KS][FM], fb[C::KS][FN];
+            if (g.epi & (1 << 22)) {     // lab ablation: fragments from registers, no LDS reads
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) { fb[ks][j] = fb[0][0]; asm volatile("" : "+v"(fb[ks][j])); }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) { fa[ks][i] = fb[0][0]; asm volatile("" : "+v"(fa[ks][i])); }
+                }
+            } else
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
 #pragma unroll
@@ -307,9 +326,26 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+            if constexpr (TA) {
+                if (do_colsum) {
+#pragma unroll
+                    for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) csum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[ks][i], csum[i], 0, 0, 0);
+                }
+            }
             c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
         }
         __builtin_amdgcn_s_barrier();   // every wave is done reading the ring: it is epilogue scratch now
+        if constexpr (TA) {
+            if (do_colsum && gq == 0) {       // csum[i][r]: column = lane&15 = m, every row identical
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int m = it.m0 + wm * FM * 16 + i * 16 + li16;
+                    if (m < g.M) atomicAdd(g.colsum_a + m, csum[i][0]);
+                }
+            }
+        }
 
         // ---- epilogue.  acc[i][j][r]: m = m0 + i*16 + (lane&15), n = n0 + j*16 + (lane>>4)*4 + r.
         // The accumulators go through a per-wave LDS image so that every lane ends up with

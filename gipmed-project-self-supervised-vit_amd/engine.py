@@ -272,8 +272,8 @@ class VitRunner:
             ops.linear(G.gb, W.w(b + "mlp.fc2.weight"), G.dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
             ops.linear(G.gb, G.h[i], W.g(b + "mlp.fc2.weight"), D, 4 * D, T, trans_a=True, trans_b=True, epilogue=ACC)
             ops.linear(G.dh, W.w(b + "mlp.fc1.weight"), G.dxn, T, D, 4 * D, trans_b=True)
-            ops.linear(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
-            ops.colsum(G.dh, T, 4 * D, self.cs_ws, W.g(b + "mlp.fc1.bias"), accumulate=True)
+            ops.linear(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC,
+                       colsum_a=W.g(b + "mlp.fc1.bias"))
             ops.layernorm_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), G.g, G.gb, self.partials, T, D)
             self._fin3(W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"))
             # attention
@@ -281,8 +281,8 @@ class VitRunner:
             ops.linear(G.gb, G.o[i], W.g(b + "attn.proj.weight"), D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
             ops.attention_bwd(G.qkv[i], G.o[i], G.do, G.lse[i], G.n_img, N, H, self.scale, dqkv=G.dqkv)
             ops.linear(G.dqkv, W.w(b + "attn.qkv.weight"), G.dxn, T, D, 3 * D, trans_b=True)
-            ops.linear(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
-            ops.colsum(G.dqkv, T, 3 * D, self.cs_ws, W.g(b + "attn.qkv.bias"), accumulate=True)
+            ops.linear(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC,
+                       colsum_a=W.g(b + "attn.qkv.bias"))
             ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, G.gb, self.partials, T, D)
             self._fin3(W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
         # token assembly + patch embedding
@@ -346,14 +346,11 @@ class HeadRunner:
         hb.dzn.zero_()         # split-K over the K=65536 classes accumulates with atomics
         ops.linear(hb.dlogits, wn, hb.dzn, R, Bt, K, trans_b=True, epilogue=ACC)
         ops.l2norm_bwd(hb.dzn, hb.zn, hb.inv, hb.dz, R, Bt)
-        ops.linear(hb.dz, hb.h2, W.g("mlp.4.weight"), Bt, Hd, R, trans_a=True, trans_b=True, epilogue=ACC)
-        ops.colsum(hb.dz, R, Bt, self.cs_ws, W.g("mlp.4.bias"), accumulate=True)
+        ops.linear(hb.dz, hb.h2, W.g("mlp.4.weight"), Bt, Hd, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.4.bias"))
         ops.linear(hb.dz, W.w("mlp.4.weight"), hb.dh2, R, Hd, Bt, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h2p)
-        ops.linear(hb.dh2, hb.h1, W.g("mlp.2.weight"), Hd, Hd, R, trans_a=True, trans_b=True, epilogue=ACC)
-        ops.colsum(hb.dh2, R, Hd, self.cs_ws, W.g("mlp.2.bias"), accumulate=True)
+        ops.linear(hb.dh2, hb.h1, W.g("mlp.2.weight"), Hd, Hd, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.2.bias"))
         ops.linear(hb.dh2, W.w("mlp.2.weight"), hb.dh1, R, Hd, Hd, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h1p)
-        ops.linear(hb.dh1, hb.feats, W.g("mlp.0.weight"), Hd, D, R, trans_a=True, trans_b=True, epilogue=ACC)
-        ops.colsum(hb.dh1, R, Hd, self.cs_ws, W.g("mlp.0.bias"), accumulate=True)
+        ops.linear(hb.dh1, hb.feats, W.g("mlp.0.weight"), Hd, D, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.0.bias"))
         ops.linear(hb.dh1, W.w("mlp.0.weight"), hb.dfeats, R, D, Hd, trans_b=True)
 
 

@@ -147,6 +147,9 @@ typedef struct {
     void* aux_out;              /* bf16 [M,N], ld = ld_aux (SAVE_PRE)        */
     const float* pos; int32_t P; /* POS: pos f32 [(P+1), N]                  */
     float alpha;                /* scales the accumulator before the epilogue*/
+    /* trans_a only: colsum_a[m] += sum_k A[k,m] (f32, atomics) -- the bias gradient of the
+     * Linear whose weight gradient this launch computes, from the tiles it stages anyway */
+    float* colsum_a;
 } gv_linear_args;
 int gv_linear(const gv_linear_args* a, void* stream);
 

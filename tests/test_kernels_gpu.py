@@ -65,8 +65,10 @@ def test_linear_tn_exact(dev, M, N, K):
     assert torch.equal(C, ref)
     # ACCUM (+ split-K with f32 atomics when the grid is small): integers stay exact
     C2 = torch.ones(M, N, dtype=f32, device=dev)
-    ops().linear(A, B, C2, M, N, K, trans_a=True, trans_b=True, epilogue=L().EPI_ACCUM)
+    cs = torch.full((M,), 2.0, device=dev)          # fused bias gradient: column sums of A
+    ops().linear(A, B, C2, M, N, K, trans_a=True, trans_b=True, epilogue=L().EPI_ACCUM, colsum_a=cs)
     assert torch.equal(C2, ref + 1.0)
+    assert torch.equal(cs, 2.0 + A.float().sum(0))
 
 
 def test_linear_epilogues(dev):

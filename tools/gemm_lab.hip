@@ -53,8 +53,8 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
         p.epi = sh.epi; p.bias = bias; p.resid = resid; p.ldr = sh.N; p.aux_in = (const bf16*)aux; p.ld_aux = sh.N; p.aux_out = (bf16*)aux;
         p.alpha = 1.f;
         float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
-        for (int v = 0; v < 4; ++v) {      // bit0: persistent, bit1: NO-STORE ablation
-            const int pm = v & 1, order = 0; p.epi = sh.epi | ((v >> 1) ? (1 << 20) : 0);
+        for (int v = 0; v < 4; ++v) {      // 0 full, 1 no-store, 2 no-store+no-global-load, 3 no-store+no-LDS-read
+            const int pm = 0, order = 0; p.epi = sh.epi | (v >= 1 ? (1 << 20) : 0) | (v == 2 ? (1 << 21) : 0) | (v == 3 ? (1 << 22) : 0);
             for (int round = 0; round < 3; ++round) {
                 float t;
                 if (!sh.ta && !sh.tb) {
@@ -70,7 +70,7 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
             }
         }
         const double fl = 2.0 * sh.M * sh.N * sh.K;
-        printf("%-20s %-19s flat: tile/wg %6.1f us %6.1f TF | persist %6.1f us %6.1f TF || NOSTORE: tile/wg %6.1f us %6.1f TF | persist %6.1f us %6.1f TF\n",
+        printf("%-20s %-19s full %6.1f us %6.1f TF | no-store %6.1f us %6.1f TF | +no-gload %6.1f us %6.1f TF | +no-ldsread %6.1f us %6.1f TF\n",
                cname, sh.name, best[0] * 1e6, fl / best[0] / 1e12, best[1] * 1e6, fl / best[1] / 1e12, best[2] * 1e6, fl / best[2] / 1e12,
                best[3] * 1e6, fl / best[3] / 1e12);
         fflush(stdout);
@@ -87,6 +87,8 @@ int main(int argc, char** argv) {
         {"dX fc1(NN)", T, 384, 1536, false, true, 0, false},
         {"dX fc2(NN)", T, 1536, 384, false, true, 0, false},
         {"dW fc1(TN,noSplit)", 1536, 384, T, true, true, 0, true},
+        {"dW~split7 (TN)", 1536, 2688, 3602, true, true, 0, true},
+        {"dW~split4 (TN)", 1536, 1536, 6304, true, true, 0, true},
     };
     std::vector<Shape> shapes;
     for (int i = 0; i < (int)all_shapes.size(); ++i) if (only_shape < 0 || only_shape == i) shapes.push_back(all_shapes[i]);
