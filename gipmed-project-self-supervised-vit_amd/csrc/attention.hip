@@ -56,10 +56,18 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
 // forward
 // ---------------------------------------------------------------------------------
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(gv_attention_fwd_args a, int n_pairs) {
-    constexpr int NQB = NKT / 2;
-    constexpr int PAIRS = NQB >= 4 ? 1 : 4 / NQB;
-    constexpr int WPP = 4 / PAIRS;
+struct FwdCfg {
+    static constexpr int NQB = NKT / 2;                           // 32-query blocks
+    static constexpr int NW = NQB >= 5 ? 8 : 4;                   // waves per workgroup
+    static constexpr int PAIRS = NQB >= NW ? 1 : (NW / NQB >= 1 ? NW / NQB : 1);
+    static constexpr int WPP = NW / PAIRS;                        // waves per (image, head) pair
+    static constexpr int ROUNDS = (NQB + WPP - 1) / WPP;          // query blocks per wave
+};
+
+template <int NKT>
+__global__ __launch_bounds__(FwdCfg<NKT>::NW * 64) void attn_fwd_kernel(gv_attention_fwd_args a, int n_pairs) {
+    using F = FwdCfg<NKT>;
+    constexpr int NQB = F::NQB, PAIRS = F::PAIRS, WPP = F::WPP, NW = F::NW, ROUNDS = F::ROUNDS;
     constexpr int NP = NKT * 16;
     constexpr int IMG = NP * 128;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -75,12 +83,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gv_attention_fwd_args a, 
         pair = pair < n_pairs ? pair : n_pairs - 1;
         const int img = pair / H, h = pair - img * H;
         const bf16* base = qkv + (long)img * N * ld + h * 64;
-        stage_rows(base + H * 64, ld, N, NP, smem + (pr * 2 + 0) * IMG, wave, 4, lane);
-        stage_rows(base + 2 * H * 64, ld, N, NP, smem + (pr * 2 + 1) * IMG, wave, 4, lane);
+        stage_rows(base + H * 64, ld, N, NP, smem + (pr * 2 + 0) * IMG, wave, NW, lane);
+        stage_rows(base + 2 * H * 64, ld, N, NP, smem + (pr * 2 + 1) * IMG, wave, NW, lane);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const int lp = wave / WPP, wq = wave % WPP;
     const int pair_raw = blockIdx.x * PAIRS + lp;
     const bool valid = pair_raw < n_pairs;
@@ -92,16 +97,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gv_attention_fwd_args a, 
     const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
     const float c = a.scale * 1.4426950408889634f;
 
-    for (int qb = wq; qb < NQB; qb += WPP) {
-        if (qb * 32 >= N) break;
-        bf16x8 qf[2][2];
+    // this wave's Q fragments for all its query blocks: issued BEFORE the staging wait so the
+    // global-load latencies of Q, K and V overlap
+    bf16x8 qf[ROUNDS][2][2];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int qb = wq + rd * WPP;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             int qrow = qb * 32 + qt * 16 + li;
             qrow = qrow < N ? qrow : N - 1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *(const bf16x8*)(qbase + (long)qrow * ld + ks * 32 + g * 8);
+            for (int ks = 0; ks < 2; ++ks) qf[rd][qt][ks] = *(const bf16x8*)(qbase + (long)qrow * ld + ks * 32 + g * 8);
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int qb = wq + rd * WPP;
+        if (qb >= NQB || qb * 32 >= N) break;
         f32x4 s[NKT][2];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -110,8 +126,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gv_attention_fwd_args a, 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 kf = read_nat(Kimg, kt * 16 + li, ks * 4 + g);
-                s[kt][0] = MFMA16(kf, qf[0][ks], s[kt][0]);
-                s[kt][1] = MFMA16(kf, qf[1][ks], s[kt][1]);
+                s[kt][0] = MFMA16(kf, qf[rd][0][ks], s[kt][0]);
+                s[kt][1] = MFMA16(kf, qf[rd][1][ks], s[kt][1]);
             }
         }
         // softmax over keys: key = kt*16 + 4g + r lives in (kt, r) of lanes {li, li+16, li+32, li+48}
@@ -139,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gv_attention_fwd_args a, 
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f((s[kt][qt][r] - mx[qt]) * c);
+                    const float p = __builtin_amdgcn_exp2f((s[kt][qt][r] - mx[qt]) * c);
                     s[kt][qt][r] = p;
                     sum[qt] += p;
                 }
@@ -234,9 +250,6 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64) void attn_bwd_ke
         dl[q] = d;
         dl[NP + q] = l;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const int lp = wave / NKB, kb = wave % NKB;        // local pair, this wave's 32-key block
     const int pair_raw = blockIdx.x * PAIRS + lp;
     const bool valid = pair_raw < n_pairs;
@@ -251,7 +264,8 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64) void attn_bwd_ke
     const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
     const float c = a.scale * 1.4426950408889634f;
 
-    // this wave's K and V fragments (B operands: lane = key, 8 consecutive d)
+    // this wave's V fragments come straight from global: issued before the staging wait so
+    // their latency overlaps the LDS-DMA of Q, K, dO and the delta pass
     bf16x8 kf[2][2], vf[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -259,10 +273,17 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64) void attn_bwd_ke
         const int keyc = key < N ? key : N - 1;
         const bf16* vrow = qkv + ((long)img * N + keyc) * ld + 2 * H * 64 + h * 64;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kf[kt][ks] = read_nat(Kimg, key, ks * 4 + g);
-            vf[kt][ks] = *(const bf16x8*)(vrow + ks * 32 + g * 8);
-        }
+        for (int ks = 0; ks < 2; ++ks) vf[kt][ks] = *(const bf16x8*)(vrow + ks * 32 + g * 8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // this wave's K fragments (B operands: lane = key, 8 consecutive d)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = kb * 32 + kt * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = read_nat(Kimg, key, ks * 4 + g);
     }
     f32x4 dv[4][2], dk[4][2];
 #pragma unroll
@@ -303,7 +324,7 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64) void attn_bwd_ke
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = kok && (q0 + r < N);
-                    const float p = ok ? exp2f(s[qt][kt][r] * c - l4[r] * 1.4426950408889634f) : 0.f;
+                    const float p = ok ? __builtin_amdgcn_exp2f(s[qt][kt][r] * c - l4[r] * 1.4426950408889634f) : 0.f;
                     pv[qt][kt][r] = p;
                     ds[qt][kt][r] = p * (dp[qt][kt][r] - d4[r]) * a.scale;
                 }
@@ -375,7 +396,7 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64) void attn_bwd_ke
 }
 
 template <int NKT> int launch_fwd(const gv_attention_fwd_args* a, hipStream_t s) {
-    constexpr int NQB = NKT / 2, PAIRS = NQB >= 4 ? 1 : 4 / NQB;
+    constexpr int PAIRS = FwdCfg<NKT>::PAIRS;
     constexpr int LDS = PAIRS * 2 * NKT * 16 * 128;
     auto kern = attn_fwd_kernel<NKT>;
     static bool done = false;
@@ -385,7 +406,7 @@ template <int NKT> int launch_fwd(const gv_attention_fwd_args* a, hipStream_t s)
         done = true;
     }
     const int n_pairs = a->n_img * a->H;
-    hipLaunchKernelGGL(kern, dim3((n_pairs + PAIRS - 1) / PAIRS), dim3(256), LDS, s, *a, n_pairs);
+    hipLaunchKernelGGL(kern, dim3((n_pairs + PAIRS - 1) / PAIRS), dim3(FwdCfg<NKT>::NW * 64), LDS, s, *a, n_pairs);
     GV_LAUNCH_CHECK("gv_attention_fwd");
     return GV_OK;
 }
