@@ -39,7 +39,7 @@ gv_colsum_args = _struct("gv_colsum_args", [
 gv_linear_args = _struct("gv_linear_args", [
     ("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldb", i64), ("ldc", i64),
     ("trans_a", i32), ("trans_b", i32), ("c_is_f32", i32), ("epilogue", i32), ("bias", vp),
-    ("resid", vp), ("ldr", i64), ("aux_in", vp), ("ld_aux", i64), ("aux_out", vp), ("pos", vp), ("P", i32), ("alpha", f32), ("colsum_a", vp)])
+    ("resid", vp), ("ldr", i64), ("aux_in", vp), ("ld_aux", i64), ("aux_out", vp), ("pos", vp), ("P", i32), ("alpha", f32), ("colsum_a", vp), ("workspace", vp), ("workspace_bytes", i64)])
 gv_attention_fwd_args = _struct("gv_attention_fwd_args", [
     ("qkv", vp), ("o", vp), ("lse", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32)])
 gv_attention_bwd_args = _struct("gv_attention_bwd_args", [
@@ -82,7 +82,7 @@ ENTRY_POINTS = {
     "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_store_f32": gv_store_f32_args, "gv_sumsq": gv_sumsq_args,
     "gv_adamw_ema": gv_adamw_ema_args,
 }
-PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target")
+PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes")
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_POS, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 LN_PARTIAL_BLOCKS = 512
@@ -106,6 +106,7 @@ def _load():
     lib.gv_version.restype = C.c_int
     lib.gv_last_error.restype = C.c_char_p
     lib.gv_target.restype = C.c_char_p
+    lib.gv_linear_workspace_bytes.restype = C.c_int64
     return lib
 
 

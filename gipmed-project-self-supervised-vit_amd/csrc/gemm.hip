@@ -71,7 +71,22 @@ int launch(const GemmP& p, hipStream_t s) {
     return GV_OK;
 }
 
+// C[m][n] += sum_s slab[s][m][n]  (split-K reduce; 16 B per lane, fully coalesced)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long MN4, int S, int N4, long ldc4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (long)gridDim.x * 256) {
+        f32x4 acc = ((const f32x4*)slab)[i];
+        for (int s2 = 1; s2 < S; ++s2) acc += ((const f32x4*)slab)[(long)s2 * MN4 + i];
+        const long m = i / N4, n4 = i - m * N4;
+        f32x4* dst = (f32x4*)C + m * ldc4 + n4;
+        *dst = *dst + acc;
+    }
+}
+
+constexpr long WORKSPACE_BYTES = 64L << 20;
+
 }  // namespace
+
+extern "C" int64_t gv_linear_workspace_bytes(void) { return WORKSPACE_BYTES; }
 
 extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     GV_REQUIRE(a && a->A && a->B && a->C, GV_E_NULL, "gv_linear: null operand");
@@ -103,6 +118,7 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     p.ksplit = 1; p.k_per_split = ((a->K + BK - 1) / BK) * BK;
     p.order = 0;
     p.colsum_a = a->colsum_a;
+    p.slab = nullptr;
     if (a->colsum_a) GV_REQUIRE(ta, GV_E_UNSUPPORTED, "gv_linear: colsum_a needs trans_a (it sums the dW product's A operand)");
     hipStream_t s = (hipStream_t)stream;
 
@@ -125,13 +141,27 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
             }
         }
     }
+    bool slab = false;
+    if (p.ksplit > 1 && a->workspace && (long)p.ksplit * a->M * a->N * 4 <= a->workspace_bytes && gv_aligned(a->workspace, 16)) {
+        p.slab = a->workspace;
+        slab = true;
+    }
+    auto finish = [&](int rc) -> int {
+        if (rc != GV_OK || !slab) return rc;
+        const long MN4 = (long)a->M * a->N / 4;
+        long blocks = (MN4 + 255) / 256; if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.slab, (float*)a->C, MN4, p.ksplit,
+                           a->N / 4, a->ldc / 4);
+        GV_LAUNCH_CHECK("gv_linear(splitk_reduce)");
+        return GV_OK;
+    };
     // specialised epilogue masks of the hot path; anything else (and any N % 4 != 0) runs the
     // runtime-mask build
     const bool generic = (a->N & 7) != 0;
     constexpr int E_B = GV_EPI_BIAS, E_BGS = GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE, E_BR = GV_EPI_BIAS | GV_EPI_RESID,
                   E_BP = GV_EPI_BIAS | GV_EPI_POS, E_DG = GV_EPI_DGELU, E_ACC = GV_EPI_ACCUM;
     if (ta && tb) {
-        if (p.ksplit > 1 && !generic) return launch<true, true, float, true, E_ACC>(p, s);
+        if (p.ksplit > 1 && !generic) return finish(launch<true, true, float, true, E_ACC>(p, s));
         if (a->c_is_f32) {
             if (!generic && e == 0) return launch<true, true, float, false, 0>(p, s);
             if (!generic && e == E_ACC) return launch<true, true, float, false, E_ACC>(p, s);
@@ -140,13 +170,13 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
         return launch<true, true, bf16, false>(p, s);
     }
     if (!ta && tb) {
-        if (p.ksplit > 1 && !generic) return launch<false, true, float, true, E_ACC>(p, s);
+        if (p.ksplit > 1 && !generic) return finish(launch<false, true, float, true, E_ACC>(p, s));
         if (a->c_is_f32) return launch<false, true, float, false>(p, s);
         if (!generic && e == 0) return launch<false, true, bf16, false, 0>(p, s);
         if (!generic && e == E_DG) return launch<false, true, bf16, false, E_DG>(p, s);
         return launch<false, true, bf16, false>(p, s);
     }
-    if (p.ksplit > 1 && !generic) return launch<false, false, float, true, E_ACC>(p, s);
+    if (p.ksplit > 1 && !generic) return finish(launch<false, false, float, true, E_ACC>(p, s));
     if (a->c_is_f32) {
         if (!generic && e == 0) return launch<false, false, float, false, 0>(p, s);
         if (!generic && e == E_B) return launch<false, false, float, false, E_B>(p, s);

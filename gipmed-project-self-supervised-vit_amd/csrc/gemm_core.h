@@ -17,6 +17,7 @@ struct GemmP {
     const float* pos; int P;
     float alpha;
     int tiles_m, tiles_n, ksplit, k_per_split;
+    float* slab;       // split-K: non-null -> partial tiles are stored here [slice][M][N] instead of atomics
     float* colsum_a;   // TA only: += column sums of A (bias gradient), computed as MFMAs against ones
     int order;   // 0: flat m-major items; 1: per-XCD M-panel ranges walked n-major (L2 reuse of A)
 };
@@ -377,7 +378,10 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
                         const int itn = ((ib * 16 + r0) / RPI) * CPI + cc;   // compile-time after unrolling
                         const bool ok = m < M && n < N;
                         if constexpr (ATOMIC) {
-                            if (ok) atomicAdd(Cf + (long)m * g.ldc + n, img[row * STRIDE + col]);
+                            if (ok) {
+                                if (g.slab) g.slab[((long)(it.kbeg / g.k_per_split) * M + m) * N + n] = img[row * STRIDE + col];
+                                else atomicAdd(Cf + (long)m * g.ldc + n, img[row * STRIDE + col]);
+                            }
                         } else {
                             const int mc = m < M ? m : M - 1, nc = n < N ? n : N - W;
                             long orow = mc; int prow = 0;

@@ -217,6 +217,7 @@ class VitRunner:
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
         self.one = torch.ones(1, dtype=f32, device=device)
+        self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
 
     # ---- forward: tiles -> CLS features written into feats[row_off : row_off + n_img]
     def forward(self, W: Weights, G: VitGroup, tiles_u8, windows, mean, std, feats, row_off: int):
@@ -270,19 +271,19 @@ class VitRunner:
             b, st = f"blocks.{i}.", G.stats[i]
             # MLP
             ops.linear(G.gb, W.w(b + "mlp.fc2.weight"), G.dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
-            ops.linear(G.gb, G.h[i], W.g(b + "mlp.fc2.weight"), D, 4 * D, T, trans_a=True, trans_b=True, epilogue=ACC)
+            ops.linear(G.gb, G.h[i], W.g(b + "mlp.fc2.weight"), D, 4 * D, T, trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
             ops.linear(G.dh, W.w(b + "mlp.fc1.weight"), G.dxn, T, D, 4 * D, trans_b=True)
             ops.linear(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC,
-                       colsum_a=W.g(b + "mlp.fc1.bias"))
+                       colsum_a=W.g(b + "mlp.fc1.bias"), workspace=self.ws)
             ops.layernorm_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), G.g, G.gb, self.partials, T, D)
             self._fin3(W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"))
             # attention
             ops.linear(G.gb, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
-            ops.linear(G.gb, G.o[i], W.g(b + "attn.proj.weight"), D, D, T, trans_a=True, trans_b=True, epilogue=ACC)
+            ops.linear(G.gb, G.o[i], W.g(b + "attn.proj.weight"), D, D, T, trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
             ops.attention_bwd(G.qkv[i], G.o[i], G.do, G.lse[i], G.n_img, N, H, self.scale, dqkv=G.dqkv)
             ops.linear(G.dqkv, W.w(b + "attn.qkv.weight"), G.dxn, T, D, 3 * D, trans_b=True)
             ops.linear(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC,
-                       colsum_a=W.g(b + "attn.qkv.bias"))
+                       colsum_a=W.g(b + "attn.qkv.bias"), workspace=self.ws)
             ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, G.gb, self.partials, T, D)
             self._fin3(W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
         # token assembly + patch embedding
@@ -290,7 +291,7 @@ class VitRunner:
         # d cls_token = sum over images of the CLS-row gradient = dpos row 0
         ops.small_matmul(self.one, G.dpos, W.g("cls_token").view(1, D), 1, D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
         ops.linear(G.gpatch, G.patches, W.g("patch_embed.proj.weight").view(D, 768), D, 768, G.n_img * P,
-                   trans_a=True, trans_b=True, epilogue=ACC)
+                   trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
         ops.colsum(G.dpos[1:], P, D, self.cs_ws, W.g("patch_embed.proj.bias"), accumulate=True)
         gpos = W.g("pos_embed").view(-1, D)
         if G.pos is None:
@@ -325,6 +326,7 @@ class HeadRunner:
     def __init__(self, D: int, K: int, hidden: int, bott: int, device):
         self.D, self.K, self.hidden, self.bott = D, K, hidden, bott
         self.cs_ws = _empty((64 * max(hidden, bott),), f32, device)
+        self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
 
     def forward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers):
         R, D, Hd, Bt, K, E = hb.R, self.D, self.hidden, self.bott, self.K, L
@@ -344,13 +346,13 @@ class HeadRunner:
             ops.weightnorm_bwd(hb.dwn, W.f("last_layer.weight_v"), W.f("last_layer.weight_g").view(-1),
                                W.g("last_layer.weight_v"), None, K, Bt, accumulate=True)
         hb.dzn.zero_()         # split-K over the K=65536 classes accumulates with atomics
-        ops.linear(hb.dlogits, wn, hb.dzn, R, Bt, K, trans_b=True, epilogue=ACC)
+        ops.linear(hb.dlogits, wn, hb.dzn, R, Bt, K, trans_b=True, epilogue=ACC, workspace=self.ws)
         ops.l2norm_bwd(hb.dzn, hb.zn, hb.inv, hb.dz, R, Bt)
-        ops.linear(hb.dz, hb.h2, W.g("mlp.4.weight"), Bt, Hd, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.4.bias"))
+        ops.linear(hb.dz, hb.h2, W.g("mlp.4.weight"), Bt, Hd, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.4.bias"), workspace=self.ws)
         ops.linear(hb.dz, W.w("mlp.4.weight"), hb.dh2, R, Hd, Bt, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h2p)
-        ops.linear(hb.dh2, hb.h1, W.g("mlp.2.weight"), Hd, Hd, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.2.bias"))
+        ops.linear(hb.dh2, hb.h1, W.g("mlp.2.weight"), Hd, Hd, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.2.bias"), workspace=self.ws)
         ops.linear(hb.dh2, W.w("mlp.2.weight"), hb.dh1, R, Hd, Hd, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h1p)
-        ops.linear(hb.dh1, hb.feats, W.g("mlp.0.weight"), Hd, D, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.0.bias"))
+        ops.linear(hb.dh1, hb.feats, W.g("mlp.0.weight"), Hd, D, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.0.bias"), workspace=self.ws)
         ops.linear(hb.dh1, W.w("mlp.0.weight"), hb.dfeats, R, D, Hd, trans_b=True)
 
 

@@ -86,7 +86,7 @@ def colsum(x, rows: int, C: int, workspace, out, accumulate: bool = False, ld: O
 
 def linear(A, B, C, M: int, N: int, K: int, *, trans_a=False, trans_b=False, epilogue=0, bias=None, resid=None,
            aux_in=None, aux_out=None, pos=None, P=0, alpha=1.0, lda=None, ldb=None, ldc=None, ldr=None, ld_aux=None,
-           colsum_a=None):
+           colsum_a=None, workspace=None):
     """C[M,N] = op(A) op(B) (+ epilogue); see include/gipvit.h gv_linear."""
     a = L.gv_linear_args()
     a.A, a.B, a.C, a.M, a.N, a.K = A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K
@@ -97,6 +97,8 @@ def linear(A, B, C, M: int, N: int, K: int, *, trans_a=False, trans_b=False, epi
     a.bias, a.resid, a.ldr = _p(bias), _p(resid), (N if ldr is None else ldr)
     a.aux_in, a.ld_aux, a.aux_out = _p(aux_in), (N if ld_aux is None else ld_aux), _p(aux_out)
     a.pos, a.P, a.alpha, a.colsum_a = _p(pos), P, alpha, _p(colsum_a)
+    if workspace is not None:
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     L.call("gv_linear", a, _stream())
     return C
 

@@ -150,7 +150,14 @@ typedef struct {
     /* trans_a only: colsum_a[m] += sum_k A[k,m] (f32, atomics) -- the bias gradient of the
      * Linear whose weight gradient this launch computes, from the tiles it stages anyway */
     float* colsum_a;
+    /* optional split-K scratch (f32, caller-owned, gv_linear_workspace_bytes() big): when given,
+     * split-K partial tiles are stored as slabs and summed into C by a second kernel instead of
+     * meeting in C through f32 atomics (the atomic volume is ~33 MB per launch at full occupancy
+     * and runs at ~1.3 TB/s; slab stores + reduce move the same bytes at HBM speed).           */
+    float* workspace; int64_t workspace_bytes;
 } gv_linear_args;
+/* upper bound of the split-K scratch gv_linear can use for any shape: 64 MiB */
+int64_t gv_linear_workspace_bytes(void);
 int gv_linear(const gv_linear_args* a, void* stream);
 
 /* ---- attention (vit.pyc@L119-131): softmax(q k^T * scale) v per (image, head)

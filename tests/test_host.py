@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from gipvit import _lib
     hdr = open(os.path.join(ROOT, "include", "gipvit.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(gv_\w+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(gv_\w+)\s*\(", hdr, re.M))
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(_lib.lib, name), f"{name} declared in gipvit.h but not exported"

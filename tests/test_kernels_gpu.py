@@ -69,6 +69,11 @@ def test_linear_tn_exact(dev, M, N, K):
     ops().linear(A, B, C2, M, N, K, trans_a=True, trans_b=True, epilogue=L().EPI_ACCUM, colsum_a=cs)
     assert torch.equal(C2, ref + 1.0)
     assert torch.equal(cs, 2.0 + A.float().sum(0))
+    # same with slab-reduced split-K (caller workspace) instead of atomics
+    ws = torch.empty(L().lib.gv_linear_workspace_bytes() // 4, dtype=f32, device=dev)
+    C3 = torch.ones(M, N, dtype=f32, device=dev)
+    ops().linear(A, B, C3, M, N, K, trans_a=True, trans_b=True, epilogue=L().EPI_ACCUM, workspace=ws)
+    assert torch.equal(C3, ref + 1.0)
 
 
 def test_linear_epilogues(dev):

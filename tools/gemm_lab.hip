@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
         {"dW fc1(TN,noSplit)", 1536, 384, T, true, true, 0, true},
         {"dW~split7 (TN)", 1536, 2688, 3602, true, true, 0, true},
         {"dW~split4 (TN)", 1536, 1536, 6304, true, true, 0, true},
+        {"dW~split14 (TN)", 1536, 5376, 1801, true, true, 0, true},
     };
     std::vector<Shape> shapes;
     for (int i = 0; i < (int)all_shapes.size(); ++i) if (only_shape < 0 || only_shape == i) shapes.push_back(all_shapes[i]);
