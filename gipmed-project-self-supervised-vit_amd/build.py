@@ -32,7 +32,7 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "gv_common.h"), os.path.join(HERE, "..", "include", "gipvit.h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "gipvit.h")]
 
     def compile_one(name):
         src, obj = os.path.join(CSRC, name + ".hip"), os.path.join(OBJ, name + ".o")

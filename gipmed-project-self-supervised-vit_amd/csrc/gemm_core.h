@@ -187,6 +187,19 @@ __device__ __forceinline__ Item make_item(const GemmP& g, const Walk& w, int idx
     return it;
 }
 
+#ifdef GV_GEMM_STAMPS
+__device__ __forceinline__ unsigned long long gv_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define GV_STAMP(var) const unsigned long long var = gv_stamp()
+#else
+#define GV_STAMP(var)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename OutT> struct OutVec;
@@ -202,6 +215,9 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
     const int wm = wave / C::WN, wn = wave % C::WN;
     const Walk wk = make_walk<C>(g);
     const int li16 = lane & 15, gq = lane >> 4;
+#ifdef GV_GEMM_STAMPS
+    GV_STAMP(t_kernel0);
+#endif
 
     for (int it_i = 0, idx = wk.first; it_i < wk.count; ++it_i, idx += wk.stride) {
         const Item it = make_item<C>(g, wk, idx);
@@ -244,6 +260,13 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         const int epi = EPI >= 0 ? EPI : g.epi;
         const int N = g.N, M = g.M;
         constexpr bool PREFETCH = !ATOMIC && EPI >= 0 && (EPI & (GV_EPI_RESID | GV_EPI_POS | GV_EPI_ACCUM | GV_EPI_DGELU)) != 0;
+        constexpr bool BIAS_EARLY = !ATOMIC && EPI >= 0 && (EPI & GV_EPI_BIAS) != 0 && CPI == 1;
+        f32x4 pre_b[W / 4 > 0 ? W / 4 : 1];
+        if constexpr (BIAS_EARLY) {
+            const int nb = n0 + lcol < N ? n0 + lcol : N - W;
+#pragma unroll
+            for (int q = 0; q < W; q += 4) pre_b[q / 4] = *(const f32x4*)(g.bias + nb + q);
+        }
         f32x4 pre_r[PREFETCH ? NIT : 1][W / 4 > 0 ? W / 4 : 1];
         bf16x8 pre_a[PREFETCH && (EPI >= 0 && (EPI & GV_EPI_DGELU)) ? NIT : 1];
         if constexpr (PREFETCH) {
@@ -284,8 +307,13 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         for (int i = 0; i < FM; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const bf16x8 ones = bf16x8{(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
 
+#ifdef GV_GEMM_STAMPS
+        unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+        GV_STAMP(t_loop0);
+#endif
         int c_stage = 0;
         for (int t = 0; t < it.nt; ++t) {
+            GV_STAMP(ts0);
             // this step's pieces (mine) landed: everything but the younger in-flight steps
             {
                 const int young = min(PD - 1, it.nt - 1 - t);
@@ -294,8 +322,11 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
                 else if (PD >= 2 && young == 1) wait_vmcnt<C::GLDS * 1>();
                 else wait_vmcnt<0>();
             }
+            GV_STAMP(ts1);
             __builtin_amdgcn_s_barrier();     // everybody's pieces landed; last step's stage is free
+            GV_STAMP(ts2);
             issue();
+            GV_STAMP(ts3);
             GV_LDS char* cur = smem + c_stage * C::STAGE;
             // all fragment reads of the stage are issued up front (KS * (FM + FN) ds_read_b128 /
             // tr reads); the MFMAs then run back-to-back behind the compiler's counted lgkmcnt(N)
@@ -336,7 +367,13 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
                 }
             }
             c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+#ifdef GV_GEMM_STAMPS
+            { GV_STAMP(ts4); c_wait += ts1 - ts0; c_bar += ts2 - ts1; c_issue += ts3 - ts2; c_comp += ts4 - ts3; }
+#endif
         }
+#ifdef GV_GEMM_STAMPS
+        GV_STAMP(t_loop1);
+#endif
         __builtin_amdgcn_s_barrier();   // every wave is done reading the ring: it is epilogue scratch now
         if constexpr (TA) {
             if (do_colsum && gq == 0) {       // csum[i][r]: column = lane&15 = m, every row identical
@@ -394,7 +431,11 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
                             }
                             if (epi & GV_EPI_BIAS) {
 #pragma unroll
-                                for (int q = 0; q < W; q += 4) { const f32x4 b = *(const f32x4*)(g.bias + nc + q); v[q] += b[0]; v[q + 1] += b[1]; v[q + 2] += b[2]; v[q + 3] += b[3]; }
+                                for (int q = 0; q < W; q += 4) {
+                                    f32x4 b;
+                                    if constexpr (BIAS_EARLY) b = pre_b[q / 4]; else b = *(const f32x4*)(g.bias + nc + q);
+                                    v[q] += b[0]; v[q + 1] += b[1]; v[q + 2] += b[2]; v[q + 3] += b[3];
+                                }
                             }
                             if (epi & GV_EPI_SAVE_PRE) {
                                 if (ok) {
@@ -467,7 +508,17 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         // Retire this item's stores with a wait the COMPILER can see (otherwise it guards the
         // store-data registers it reuses in the next k-loop with its own vmcnt(0) per k-step),
         // and let every wave leave its image before the next item's LDS-DMA overwrites it.
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        if (it_i + 1 < wk.count) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); a wave that exits next needs no wait
+#ifdef GV_GEMM_STAMPS
+        {   // stamps leave through a buffer of their own (g.pos is unused by the lab shapes)
+            GV_STAMP(t_end);
+            if (lane == 0 && g.pos) {
+                float* o = (float*)g.pos + ((long)blockIdx.x * C::NW + wave) * 8;
+                o[0] = (float)c_wait; o[1] = (float)c_bar; o[2] = (float)c_issue; o[3] = (float)c_comp;
+                o[4] = (float)(t_loop1 - t_loop0); o[5] = (float)(t_end - t_loop1); o[6] = (float)(t_loop0 - t_kernel0); o[7] = (float)it.nt;
+            }
+        }
+#endif
         if (it_i + 1 < wk.count) __builtin_amdgcn_s_barrier();
     }
 }

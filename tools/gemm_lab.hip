@@ -38,6 +38,16 @@ float run_cfg(const Shape& sh, GemmP p, int reps, int persistent_mult, int order
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipGetLastError());
+#ifdef GV_GEMM_STAMPS
+    if (p.pos) {
+        std::vector<float> h((size_t)grid * C::NW * 8);
+        CK(hipMemcpy(h.data(), p.pos, h.size() * 4, hipMemcpyDeviceToHost));
+        double a[8] = {0}; size_t n = h.size() / 8;
+        for (size_t i = 0; i < n; ++i) for (int j = 0; j < 8; ++j) a[j] += h[i * 8 + j];
+        printf("   stamps/wave (cycles): prologue %.0f | k-loop %.0f = wait %.0f + barrier %.0f + issue %.0f + read+mfma %.0f (steps %.0f) | epilogue %.0f\n",
+               a[6] / n, a[4] / n, a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[7] / n, a[5] / n);
+    }
+#endif
     return ms * 1e-3f / reps;
 }
 
@@ -52,6 +62,9 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
         p.lda = sh.ta ? sh.M : sh.K; p.ldb = sh.tb ? sh.N : sh.K; p.ldc = sh.N;
         p.epi = sh.epi; p.bias = bias; p.resid = resid; p.ldr = sh.N; p.aux_in = (const bf16*)aux; p.ld_aux = sh.N; p.aux_out = (bf16*)aux;
         p.alpha = 1.f;
+#ifdef GV_GEMM_STAMPS
+        p.pos = resid;   // stamp sink (lab shapes never use POS); resid doubles as scratch here
+#endif
         float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
         for (int v = 0; v < 4; ++v) {      // 0 full, 1 no-store, 2 no-store+no-global-load, 3 no-store+no-LDS-read
             const int pm = 0, order = 0; p.epi = sh.epi | (v >= 1 ? (1 << 20) : 0) | (v == 2 ? (1 << 21) : 0) | (v == 3 ? (1 << 22) : 0);
