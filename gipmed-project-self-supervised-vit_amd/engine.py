@@ -258,7 +258,9 @@ class VitRunner:
         ops.ln_finalize(self.partials, L.LN_PARTIAL_BLOCKS, self.D, dgamma, dbeta, dbias)
 
     # ---- backward from d(CLS features) bf16 [n_img, D]; gradients ACCUMULATE into the arena
-    def backward(self, W: Weights, G: VitGroup, dfeat: torch.Tensor):
+    def backward(self, W: Weights, G: VitGroup, dfeat: torch.Tensor, on_block_done=None):
+        """``on_block_done(i)`` is called once block i's parameter gradients are complete for this
+        group (data-parallel engines start that block's all-reduce there)."""
         D, T, N, P, H = self.D, G.T, G.N, G.P, self.H
         E = L
         ACC = E.EPI_ACCUM
@@ -286,6 +288,8 @@ class VitRunner:
                        colsum_a=W.g(b + "attn.qkv.bias"), workspace=self.ws)
             ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, G.gb, self.partials, T, D)
             self._fin3(W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
+            if on_block_done is not None:
+                on_block_done(i)
         # token assembly + patch embedding
         ops.tokens_bwd(G.g, G.gpatch, G.dpos, None, G.n_img, N, D, accumulate=False)
         # d cls_token = sum over images of the CLS-row gradient = dpos row 0
@@ -417,6 +421,12 @@ class DinoEngine:
         self.reducer = reducer if reducer is not None else NoReducer()
         self.graph = None
         self._static_tiles = None
+        # contiguous arena range of every block's weight-decayed matrices (arena order = backward order)
+        self._block_range = {}
+        for i in range(ARCHS[arch]["depth"]):
+            names = [n for n in self.arena.order if n.startswith(f"backbone.blocks.{i}.") and self.arena.off[n] < self.arena.n_decay]
+            self._block_range[i] = (min(self.arena.off[n] for n in names),
+                                    max(self.arena.off[n] + _round_up(math.prod(self.arena.specs[n]), PAD) for n in names))
 
     # ---- parameters ----------------------------------------------------------------
     def load_state(self, backbone: Dict[str, torch.Tensor], head: Dict[str, torch.Tensor]):
@@ -490,8 +500,18 @@ class DinoEngine:
             self._reduced_hi = 0
         if self.g_loc is not None:
             self.vit.backward(self.sW, self.g_loc, self.hb_s.dfeats[G * B:])
-        self.vit.backward(self.sW, self.g_glob, self.hb_s.dfeats[:G * B])
-        self.reducer.reduce_range(a.g, self._reduced_hi, a.n)
+        # last group: every block's weight gradients are final when its backward ends -> reduce that
+        # block's contiguous arena range right away (RCCL's stream runs beside the remaining backward)
+        state = {"hi": self._reduced_hi}
+
+        def block_done(i):
+            lo, hi = self._block_range[i]
+            if self.reducer.world > 1:
+                self.reducer.reduce_range(a.g, min(lo, state["hi"]), hi)
+                state["hi"] = hi
+
+        self.vit.backward(self.sW, self.g_glob, self.hb_s.dfeats[:G * B], on_block_done=block_done)
+        self.reducer.reduce_range(a.g, state["hi"], a.n)          # patch embed + the no-decay segment
         self.reducer.finish()
 
     def optimizer_step(self):
