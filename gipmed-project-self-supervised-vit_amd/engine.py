@@ -168,39 +168,62 @@ def pos_interp_matrix(n_src_side: int, crop: int) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- #
-# activations of one crop group
+# activations of a crop group: one or more SEGMENTS (crop resolutions) whose tokens are
+# concatenated -- every token-wise op (LayerNorm, all GEMMs, dW) then runs ONCE over all rows;
+# only attention, patch embedding and the CLS handling run per segment (multi-crop wrapper, row D1)
 # --------------------------------------------------------------------------- #
-class VitGroup:
-    def __init__(self, arch: str, n_img: int, crop: int, img_size: int, device, save: bool):
-        a = ARCHS[arch]
-        D, depth, H = a["embed_dim"], a["depth"], a["num_heads"]
-        self.n_img, self.crop, self.save = n_img, crop, save
+class Segment:
+    def __init__(self, arch, n_img, crop, img_size, row0, img0, device, save, depth, H):
+        D = ARCHS[arch]["embed_dim"]
+        self.n_img, self.crop, self.row0, self.img0 = n_img, crop, row0, img0
         self.P = (crop // 16) ** 2
         self.N = self.P + 1
         self.T = n_img * self.N
+        e = lambda shape, dt: _empty(shape, dt, device)
+        nb = depth if save else 1
+        self.patches = e((n_img * self.P, 768), bf16)
+        self.lse = [e((n_img, H, self.N), f32) for _ in range(nb)]
+        self.fstats = [e((n_img,), f32) for _ in range(2)]
+        self.pos = None if crop == img_size else e((self.N, D), f32)
+        self.interp = None if crop == img_size else pos_interp_matrix(img_size // 16, crop).to(device)
+        if save:
+            self.gpatch = e((n_img * self.P, D), bf16)
+            self.dpos = e((self.N, D), f32)
+
+    def rows(self, t: torch.Tensor) -> torch.Tensor:
+        return t[self.row0:self.row0 + self.T]
+
+
+class VitGroup:
+    def __init__(self, arch: str, segments, img_size: int, device, save: bool):
+        """segments: [(n_img, crop), ...] in feature-row order."""
+        a = ARCHS[arch]
+        D, depth, H = a["embed_dim"], a["depth"], a["num_heads"]
+        self.save = save
+        self.segs: List[Segment] = []
+        row0 = img0 = 0
+        for n_img, crop in segments:
+            sg = Segment(arch, n_img, crop, img_size, row0, img0, device, save, depth, H)
+            self.segs.append(sg)
+            row0 += sg.T
+            img0 += n_img
+        self.T, self.n_img = row0, img0
         T, nb = self.T, (depth if save else 1)
         e = lambda shape, dt: _empty(shape, dt, device)
-        self.patches = e((n_img * self.P, 768), bf16)
         self.x = [e((T, D), f32) for _ in range(2 * depth + 1 if save else 3)]
         self.xn1 = [e((T, D), bf16) for _ in range(nb)]
         self.xn2 = [e((T, D), bf16) for _ in range(nb)]
         self.qkv = [e((T, 3 * D), bf16) for _ in range(nb)]
         self.o = [e((T, D), bf16) for _ in range(nb)]
-        self.lse = [e((n_img, H, self.N), f32) for _ in range(nb)]
         self.hp = [e((T, 4 * D), bf16) for _ in range(nb)]
         self.h = [e((T, 4 * D), bf16) for _ in range(nb)]
         self.stats = [[e((T,), f32) for _ in range(4)] for _ in range(nb)]   # mean1, rstd1, mean2, rstd2
-        self.fstats = [e((n_img,), f32) for _ in range(2)]
-        self.pos = None if crop == img_size else e((self.N, D), f32)
-        self.interp = None if crop == img_size else pos_interp_matrix(img_size // 16, crop).to(device)
         if save:   # backward scratch
             self.g, self.gb = e((T, D), f32), e((T, D), bf16)
             self.dh = e((T, 4 * D), bf16)
             self.dxn = e((T, D), bf16)
             self.dqkv = e((T, 3 * D), bf16)
             self.do = e((T, D), bf16)
-            self.gpatch = e((n_img * self.P, D), bf16)
-            self.dpos = e((self.N, D), f32)
 
     def xbuf(self, j):
         return self.x[j] if self.save else self.x[j % 3]
@@ -219,30 +242,34 @@ class VitRunner:
         self.one = torch.ones(1, dtype=f32, device=device)
         self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
 
-    # ---- forward: tiles -> CLS features written into feats[row_off : row_off + n_img]
-    def forward(self, W: Weights, G: VitGroup, tiles_u8, windows, mean, std, feats, row_off: int):
-        D, T, N, P, H = self.D, G.T, G.N, G.P, self.H
+    # ---- forward: tiles -> CLS features written into feats[row_off + seg.img0 ...]
+    def forward(self, W: Weights, G: VitGroup, tiles_u8, windows, mean, std, feats, row_off: int = 0):
+        """windows: one list of (y0, x0) crop origins per segment."""
+        D, T, H = self.D, G.T, self.H
         E = L
-        ops.patchify(tiles_u8, windows, G.crop, mean, std, out=G.patches)
         pos_full = W.f("pos_embed").view(-1, D)
-        if G.pos is None:
-            pos = pos_full
-        else:   # interpolate_pos_encoding: row 0 = cls pos, rows 1.. = M @ pos[1:]
-            pos = G.pos
-            Ps = pos_full.shape[0] - 1
-            ops.small_matmul(self.one, pos_full, pos, 1, D, 1, sam=0, sak=0, sbk=0, sbn=1)
-            ops.small_matmul(G.interp, pos_full[1:], pos[1:], P, D, Ps, sam=Ps, sak=1, sbk=D, sbn=1)
         x0 = G.xbuf(0)
-        ops.cls_rows(x0, W.f("cls_token").view(-1), pos, G.n_img, N, D)
-        ops.linear(G.patches, W.w("patch_embed.proj.weight").view(D, 768), x0, G.n_img * P, D, 768,
-                   epilogue=E.EPI_BIAS | E.EPI_POS, bias=W.f("patch_embed.proj.bias"), pos=pos, P=P)
+        for sg, wins in zip(G.segs, windows):
+            ops.patchify(tiles_u8, wins, sg.crop, mean, std, out=sg.patches)
+            if sg.pos is None:
+                pos = pos_full
+            else:   # interpolate_pos_encoding: row 0 = cls pos, rows 1.. = M @ pos[1:]
+                pos = sg.pos
+                Ps = pos_full.shape[0] - 1
+                ops.small_matmul(self.one, pos_full, pos, 1, D, 1, sam=0, sak=0, sbk=0, sbn=1)
+                ops.small_matmul(sg.interp, pos_full[1:], pos[1:], sg.P, D, Ps, sam=Ps, sak=1, sbk=D, sbn=1)
+            xs = sg.rows(x0)
+            ops.cls_rows(xs, W.f("cls_token").view(-1), pos, sg.n_img, sg.N, D)
+            ops.linear(sg.patches, W.w("patch_embed.proj.weight").view(D, 768), xs, sg.n_img * sg.P, D, 768,
+                       epilogue=E.EPI_BIAS | E.EPI_POS, bias=W.f("patch_embed.proj.bias"), pos=pos, P=sg.P)
         for i in range(self.depth):
             b, s = f"blocks.{i}.", G.slot(i)
             xa, xb, xc = G.xbuf(2 * i), G.xbuf(2 * i + 1), G.xbuf(2 * i + 2)
             st = G.stats[s]
             ops.layernorm_fwd(xa, W.f(b + "norm1.weight"), W.f(b + "norm1.bias"), T, D, y=G.xn1[s], mean=st[0], rstd=st[1])
             ops.linear(G.xn1[s], W.w(b + "attn.qkv.weight"), G.qkv[s], T, 3 * D, D, epilogue=E.EPI_BIAS, bias=W.f(b + "attn.qkv.bias"))
-            ops.attention_fwd(G.qkv[s], G.n_img, N, H, self.scale, o=G.o[s], lse=G.lse[s])
+            for sg in G.segs:
+                ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s])
             ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
                        bias=W.f(b + "attn.proj.bias"), resid=xa)
             ops.layernorm_fwd(xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), T, D, y=G.xn2[s], mean=st[2], rstd=st[3])
@@ -251,24 +278,27 @@ class VitRunner:
             ops.linear(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
                        bias=W.f(b + "mlp.fc2.bias"), resid=xb)
         xl = G.xbuf(2 * self.depth)
-        ops.layernorm_fwd(xl, W.f("norm.weight"), W.f("norm.bias"), G.n_img, D, x_stride=N * D,
-                          y=feats[row_off:row_off + G.n_img], mean=G.fstats[0], rstd=G.fstats[1])
+        for sg in G.segs:
+            r0 = row_off + sg.img0
+            ops.layernorm_fwd(sg.rows(xl), W.f("norm.weight"), W.f("norm.bias"), sg.n_img, D, x_stride=sg.N * D,
+                              y=feats[r0:r0 + sg.n_img], mean=sg.fstats[0], rstd=sg.fstats[1])
 
     def _fin3(self, dgamma, dbeta, dbias):
         ops.ln_finalize(self.partials, L.LN_PARTIAL_BLOCKS, self.D, dgamma, dbeta, dbias)
 
-    # ---- backward from d(CLS features) bf16 [n_img, D]; gradients ACCUMULATE into the arena
+    # ---- backward from d(CLS features) bf16 [G.n_img, D]; gradients ACCUMULATE into the arena
     def backward(self, W: Weights, G: VitGroup, dfeat: torch.Tensor, on_block_done=None):
-        """``on_block_done(i)`` is called once block i's parameter gradients are complete for this
-        group (data-parallel engines start that block's all-reduce there)."""
-        D, T, N, P, H = self.D, G.T, G.N, G.P, self.H
+        """``on_block_done(i)`` is called once block i's parameter gradients are complete
+        (data-parallel engines start that block's all-reduce there)."""
+        D, T, H = self.D, G.T, self.H
         E = L
         ACC = E.EPI_ACCUM
         G.g.zero_(); G.gb.zero_()
         xl = G.x[2 * self.depth]
-        ops.layernorm_bwd(dfeat, xl, G.fstats[0], G.fstats[1], W.f("norm.weight"), G.g, G.gb, self.partials, G.n_img, D,
-                          x_stride=N * D, g_stride=N * D, gb_stride=N * D, g_init=True)
-        self._fin3(W.g("norm.weight"), W.g("norm.bias"), W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
+        for sg in G.segs:
+            ops.layernorm_bwd(dfeat[sg.img0:sg.img0 + sg.n_img], sg.rows(xl), sg.fstats[0], sg.fstats[1], W.f("norm.weight"), sg.rows(G.g),
+                              sg.rows(G.gb), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True)
+            self._fin3(W.g("norm.weight"), W.g("norm.bias"), W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
         for i in reversed(range(self.depth)):
             b, st = f"blocks.{i}.", G.stats[i]
             # MLP
@@ -282,7 +312,8 @@ class VitRunner:
             # attention
             ops.linear(G.gb, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             ops.linear(G.gb, G.o[i], W.g(b + "attn.proj.weight"), D, D, T, trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
-            ops.attention_bwd(G.qkv[i], G.o[i], G.do, G.lse[i], G.n_img, N, H, self.scale, dqkv=G.dqkv)
+            for sg in G.segs:
+                ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(G.dqkv))
             ops.linear(G.dqkv, W.w(b + "attn.qkv.weight"), G.dxn, T, D, 3 * D, trans_b=True)
             ops.linear(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC,
                        colsum_a=W.g(b + "attn.qkv.bias"), workspace=self.ws)
@@ -290,20 +321,21 @@ class VitRunner:
             self._fin3(W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
             if on_block_done is not None:
                 on_block_done(i)
-        # token assembly + patch embedding
-        ops.tokens_bwd(G.g, G.gpatch, G.dpos, None, G.n_img, N, D, accumulate=False)
-        # d cls_token = sum over images of the CLS-row gradient = dpos row 0
-        ops.small_matmul(self.one, G.dpos, W.g("cls_token").view(1, D), 1, D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
-        ops.linear(G.gpatch, G.patches, W.g("patch_embed.proj.weight").view(D, 768), D, 768, G.n_img * P,
-                   trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
-        ops.colsum(G.dpos[1:], P, D, self.cs_ws, W.g("patch_embed.proj.bias"), accumulate=True)
+        # token assembly + patch embedding, per segment
         gpos = W.g("pos_embed").view(-1, D)
-        if G.pos is None:
-            ops.small_matmul(self.one, G.dpos, gpos, 1, N * D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
-        else:
-            Ps = gpos.shape[0] - 1
-            ops.small_matmul(self.one, G.dpos, gpos, 1, D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
-            ops.small_matmul(G.interp, G.dpos[1:], gpos[1:], Ps, D, P, sam=1, sak=Ps, sbk=D, sbn=1, accumulate=True)
+        for sg in G.segs:
+            ops.tokens_bwd(sg.rows(G.g), sg.gpatch, sg.dpos, None, sg.n_img, sg.N, D, accumulate=False)
+            # d cls_token = sum over images of the CLS-row gradient = dpos row 0
+            ops.small_matmul(self.one, sg.dpos, W.g("cls_token").view(1, D), 1, D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
+            ops.linear(sg.gpatch, sg.patches, W.g("patch_embed.proj.weight").view(D, 768), D, 768, sg.n_img * sg.P,
+                       trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
+            ops.colsum(sg.dpos[1:], sg.P, D, self.cs_ws, W.g("patch_embed.proj.bias"), accumulate=True)
+            if sg.pos is None:
+                ops.small_matmul(self.one, sg.dpos, gpos, 1, sg.N * D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
+            else:
+                Ps = gpos.shape[0] - 1
+                ops.small_matmul(self.one, sg.dpos, gpos, 1, D, 1, sam=0, sak=0, sbk=0, sbn=1, accumulate=True)
+                ops.small_matmul(sg.interp, sg.dpos[1:], gpos[1:], Ps, D, sg.P, sam=1, sak=Ps, sbk=D, sbn=1, accumulate=True)
 
 
 # --------------------------------------------------------------------------- #
@@ -400,9 +432,10 @@ class DinoEngine:
         self.vit = VitRunner(arch, img_size, dev)
         self.head = HeadRunner(D, out_dim, hidden, bottleneck, dev)
         B = batch
-        self.g_glob = VitGroup(arch, n_global * B, gsize, img_size, dev, save=True)
-        self.g_loc = VitGroup(arch, n_local * B, lsize, img_size, dev, save=True) if n_local else None
-        self.g_teach = VitGroup(arch, n_global * B, gsize, img_size, dev, save=False)
+        segs = [(n_global * B, gsize)] + ([(n_local * B, lsize)] if n_local else [])
+        self.g_stu = VitGroup(arch, segs, img_size, dev, save=True)            # all student crops, tokens concatenated
+        self.g_teach = VitGroup(arch, [(n_global * B, gsize)], img_size, dev, save=False)
+        self.s_wins = [self.gwins] + ([self.lwins] if n_local else [])
         self.hb_s = HeadBuffers(self.V * B, D, out_dim, hidden, bottleneck, dev, save=True)
         self.hb_t = HeadBuffers(n_global * B, D, out_dim, hidden, bottleneck, dev, save=False)
         self.wn_s = _empty((out_dim, bottleneck), bf16, dev)
@@ -479,11 +512,9 @@ class DinoEngine:
         B, G, V = self.B, self.G, self.V
         a = self.arena
         a.g.zero_()
-        self.vit.forward(self.tW, self.g_teach, tiles_u8, self.gwins, self.mean, self.std, self.hb_t.feats, 0)
+        self.vit.forward(self.tW, self.g_teach, tiles_u8, [self.gwins], self.mean, self.std, self.hb_t.feats)
         self.head.forward(self.tH, self.wn_t, self.hb_t)
-        self.vit.forward(self.sW, self.g_glob, tiles_u8, self.gwins, self.mean, self.std, self.hb_s.feats, 0)
-        if self.g_loc is not None:
-            self.vit.forward(self.sW, self.g_loc, tiles_u8, self.lwins, self.mean, self.std, self.hb_s.feats, G * B)
+        self.vit.forward(self.sW, self.g_stu, tiles_u8, self.s_wins, self.mean, self.std, self.hb_s.feats)
         self.head.forward(self.sH, self.wn_s, self.hb_s)
         ops.dino_loss(self.hb_s.logits, self.hb_t.logits, self.center, self.hb_s.dlogits, self.loss, self.center_sum,
                       self.loss_ws, B, V, G, self.K, self.ts, self.tt, hyper=self.hyper)
@@ -498,10 +529,8 @@ class DinoEngine:
             self._reduced_hi = hi
         else:
             self._reduced_hi = 0
-        if self.g_loc is not None:
-            self.vit.backward(self.sW, self.g_loc, self.hb_s.dfeats[G * B:])
-        # last group: every block's weight gradients are final when its backward ends -> reduce that
-        # block's contiguous arena range right away (RCCL's stream runs beside the remaining backward)
+        # every block's weight gradients are final when its backward ends -> reduce that block's
+        # contiguous arena range right away (RCCL's stream runs beside the remaining backward)
         state = {"hi": self._reduced_hi}
 
         def block_done(i):
@@ -510,7 +539,7 @@ class DinoEngine:
                 self.reducer.reduce_range(a.g, min(lo, state["hi"]), hi)
                 state["hi"] = hi
 
-        self.vit.backward(self.sW, self.g_glob, self.hb_s.dfeats[:G * B], on_block_done=block_done)
+        self.vit.backward(self.sW, self.g_stu, self.hb_s.dfeats, on_block_done=block_done)
         self.reducer.reduce_range(a.g, state["hi"], a.n)          # patch embed + the no-decay segment
         self.reducer.finish()
 
@@ -588,7 +617,7 @@ class SupervisedEngine:
         self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
         self.W = Weights(self.arena, "")
         self.vit = VitRunner(arch, img_size, dev)
-        self.grp = VitGroup(arch, batch, img_size, img_size, dev, save=True)
+        self.grp = VitGroup(arch, [(batch, img_size)], img_size, dev, save=True)
         e = lambda shape, dt: _empty(shape, dt, dev)
         self.feats, self.dfeats = e((batch, D), bf16), e((batch, D), bf16)
         self.logits, self.dlogits, self.prob = e((batch, num_classes), f32), e((batch, num_classes), f32), e((batch, num_classes), f32)
@@ -619,7 +648,7 @@ class SupervisedEngine:
     def forward(self, tiles_u8):
         """Inference / features: returns (logits f32 [B,C], CLS features bf16 [B,D])."""
         B, C, D, W = self.B, self.C, self.D, self.W
-        self.vit.forward(W, self.grp, tiles_u8, [(0, 0)], self.mean, self.std, self.feats, 0)
+        self.vit.forward(W, self.grp, tiles_u8, [[(0, 0)]], self.mean, self.std, self.feats)
         ops.small_matmul(self.feats, W.f("head.weight"), self.logits, B, C, D, sam=D, sak=1, sbk=1, sbn=D, bias=W.f("head.bias"))
         return self.logits, self.feats
 

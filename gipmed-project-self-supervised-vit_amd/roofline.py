@@ -38,7 +38,7 @@ def _time_linear(M, N, K, epilogue, dev, reps=20):
 def dominant_kernel_roofline(eng, batch):
     dev = eng.dev
     D, depth = eng.D, eng.vit.depth
-    groups = [(eng.g_teach.T, 1), (eng.g_glob.T, 1)] + ([(eng.g_loc.T, 1)] if eng.g_loc is not None else [])
+    groups = [(eng.g_teach.T, 1), (eng.g_stu.T, 1)]
     shapes = {}
     for T, _ in groups:
         for (N, epi) in ((3 * D, L.EPI_BIAS), (4 * D, L.EPI_BIAS | L.EPI_GELU | L.EPI_SAVE_PRE)):
