@@ -67,7 +67,6 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) kept for command-line compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-loss", action="store_true", help="debug: synchronise and print the loss after every step")
-    ap.add_argument("--kernel-timing", action="store_true", help="time the dominant GEMM with HIP events for the roofline object")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
@@ -142,7 +141,7 @@ def main():
             if args.arch == "vit_small" else None,
             "final_loss": round(loss, 4),
         }
-        out["roofline"] = roofline.dominant_kernel_roofline(eng, args.batch) if world == 1 else None
+        out["roofline"] = roofline.dominant_kernel_roofline(lambda: eng.step(tiles), steps=3) if world == 1 else None
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch, n_local)
         print(json.dumps(out), flush=True)
     if world > 1:

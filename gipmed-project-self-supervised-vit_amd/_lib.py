@@ -82,7 +82,12 @@ ENTRY_POINTS = {
     "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_store_f32": gv_store_f32_args, "gv_sumsq": gv_sumsq_args,
     "gv_adamw_ema": gv_adamw_ema_args,
 }
-PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes")
+PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read")
+
+
+class gv_linear_timing_row(C.Structure):
+    _fields_ = [("key", C.c_int32), ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("c_is_f32", C.c_int32), ("splitk", C.c_int32),
+                ("epilogue", C.c_int32), ("launches", C.c_int32), ("seconds", C.c_double), ("flops", C.c_double)]
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_POS, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 LN_PARTIAL_BLOCKS = 512
@@ -107,6 +112,10 @@ def _load():
     lib.gv_last_error.restype = C.c_char_p
     lib.gv_target.restype = C.c_char_p
     lib.gv_linear_workspace_bytes.restype = C.c_int64
+    lib.gv_linear_timing.argtypes = [C.c_int]
+    lib.gv_linear_timing.restype = C.c_int
+    lib.gv_linear_timing_read.argtypes = [C.POINTER(gv_linear_timing_row), C.c_int]
+    lib.gv_linear_timing_read.restype = C.c_int
     return lib
 
 

@@ -4,26 +4,34 @@
 // reference's ViT blocks, patch embedding and DINOHead (vit.pyc@L98-104, L119-131,
 // L167-170, L326-330; reference train.py:1045 forward, :1071 backward).
 //
-// The path's GEMMs are skinny: tens of thousands of token rows against K = 384..2048, so a
-// tile has only 12..64 k-steps and a tile-per-workgroup kernel spends its life in pipeline
-// fill/drain (measured: 17 % of MFMA peak).  Design (MI355X_MICROARCH / cdna_hip_programming 5):
-//   * PERSISTENT workgroups (2 per CU) walk a list of 128x128 output tiles; a 4-stage LDS ring
-//     is filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) three k-steps
-//     ahead of the MFMAs, ACROSS tile boundaries, behind counted s_waitcnt vmcnt(N) and one raw
-//     s_barrier per k-step -- the epilogue of tile t overlaps the loads of tile t+1, and the
-//     second workgroup on the CU fills the MFMA pipe meanwhile.
-//   * BK = 32, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16.
+// The path's GEMMs are skinny: tens of thousands of token rows against K = 384..2048 (6..32
+// k-steps per tile), or -- for the weight gradients -- a tiny output reduced over all tokens.
+// Design (MI355X_MICROARCH / cdna_hip_programming section 5; geometry, ring depth and schedule
+// were chosen with tools/gemm_lab.hip on MI355X, numbers in DESIGN.md):
+//   * one 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 v_mfma_f32_16x16x32_bf16 per
+//     32-deep k-step) per 128x128 output tile, 2 workgroups per CU: the partner workgroup's
+//     k-loop covers this one's prologue / epilogue.  BK = 64, 2-stage LDS ring (64 KiB).
+//   * the ring is filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, issued
+//     from inline asm so hipcc's waitcnt pass does not drain it) one k-step ahead of the MFMAs,
+//     behind a hand-counted s_waitcnt vmcnt(N) and ONE raw s_barrier per k-step.
 //   * the LDS image is lane-linear, so bank swizzles are applied to the per-lane SOURCE address
 //     and again on the read (rule 21):
-//       "natural" operand (reduction index contiguous, x[M,K], W[N,K]): 64-B rows, 16-B chunk
-//        index XOR ((row>>3)&1)<<1 -> conflict-free ds_read_b128;
+//       "natural" operand (reduction index contiguous, x[M,K], W[N,K]): 128-B rows, 16-B chunk
+//        index XOR (row & 7) -> conflict-free ds_read_b128;
 //       "transposed" operand (reduction index strided: dY[tokens,N] for dW, W[N,K] for dX):
-//        [32 k][128 cols] image, 32-B chunk index XOR f(k), fragments by two
+//        [64 k][128 cols] image, 32-B chunk index XOR f(k), fragments by two
 //        ds_read_b64_tr_b16 (hardware transpose) -- no transposed copies in HBM.
 //   * MFMA roles are swapped (weight fragment as the A operand) so each lane ends up with 4
-//     consecutive output columns: 8-B (bf16) / 16-B (f32) stores.
-//   * split-K (dW over tens of thousands of tokens, dX of the 65536-class head) accumulates
-//     with f32 atomics shaped as 256 contiguous bytes per wave-instruction via an LDS image.
+//     consecutive output columns; the accumulators then pass through a per-wave LDS image so
+//     that bias / residual / saved-activation loads and all stores are whole 128..256-B row
+//     segments.  Epilogue operands (residual, pos-embed, dGELU input, bias) are fetched BEFORE
+//     the k-loop; the epilogue mask is a template parameter (a runtime mask cost a load + wait
+//     per element).  GELU / GELU' are clamped odd polynomials (gv_common.h), no transcendentals.
+//   * split-K (dW over tens of thousands of tokens, dX of the 65536-class head): partial tiles
+//     go to a caller-provided slab with plain row stores and a reduce kernel adds them into C
+//     (f32 atomics run at ~1.3 TB/s on this part; they remain the fallback without a workspace).
+//     The bias gradient (column sums of dY) rides along as one extra MFMA per A fragment
+//     against a ones fragment.
 //   * workgroup -> tile map is XCD-aware: each XCD's workgroups walk a contiguous band of tiles.
 #ifndef GV_GEMM_BM
 #define GV_GEMM_BM 128
@@ -34,6 +42,8 @@
 #define GV_GEMM_NSTAGE 2
 #endif
 #include "gemm_core.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -51,6 +61,26 @@ __global__ __launch_bounds__(PCfg::THREADS, PCfg::THREADS * WGS_PER_CU / 256) vo
     gemm_body<PCfg, TA, TB, OutT, ATOMIC, EPI>(g, (GV_LDS char*)smem_raw);
 }
 
+// ---- live per-kernel timing (gv_linear_timing, include/gipvit.h): HIP events around every
+// GEMM launch on the launch stream, keyed by template instantiation.  Off by default.
+struct TimingRec { int key; hipEvent_t e0, e1; double flops; };
+struct Timing {
+    std::mutex mu;
+    bool on = false;
+    std::vector<TimingRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+Timing& timing() { static Timing t; return t; }
+
+template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI>
+constexpr int timing_key() { return (TA ? 1 : 0) | (TB ? 2 : 0) | (sizeof(OutT) == 4 ? 4 : 0) | (ATOMIC ? 8 : 0) | ((EPI & 0xFF) << 4); }
+
 template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI = -1>
 int launch(const GemmP& p, hipStream_t s) {
     auto kern = gemm_kernel<TA, TB, OutT, ATOMIC, EPI>;
@@ -66,7 +96,17 @@ int launch(const GemmP& p, hipStream_t s) {
     // measured (tools/gemm_lab): with K = 384..2048 one workgroup per item beats a persistent walk
     const int grid = items;
     (void)PERSISTENT_GRID;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), PCfg::LDS, s, p);
+    Timing& tm = timing();
+    if (tm.on) {
+        std::lock_guard<std::mutex> lk(tm.mu);
+        TimingRec r{timing_key<TA, TB, OutT, ATOMIC, EPI>(), tm.get(), tm.get(), 2.0 * p.M * p.N * p.K};
+        (void)hipEventRecord(r.e0, s);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), PCfg::LDS, s, p);
+        (void)hipEventRecord(r.e1, s);
+        tm.recs.push_back(r);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), PCfg::LDS, s, p);
+    }
     GV_LAUNCH_CHECK("gv_linear");
     return GV_OK;
 }
@@ -87,6 +127,41 @@ constexpr long WORKSPACE_BYTES = 64L << 20;
 }  // namespace
 
 extern "C" int64_t gv_linear_workspace_bytes(void) { return WORKSPACE_BYTES; }
+
+extern "C" int gv_linear_timing(int enable) {
+    Timing& tm = timing();
+    std::lock_guard<std::mutex> lk(tm.mu);
+    if (enable) {
+        for (auto& r : tm.recs) { tm.pool.push_back(r.e0); tm.pool.push_back(r.e1); }
+        tm.recs.clear();
+    }
+    tm.on = enable != 0;
+    return GV_OK;
+}
+
+extern "C" int gv_linear_timing_read(gv_linear_timing_row* rows, int max_rows) {
+    GV_REQUIRE(rows && max_rows > 0, GV_E_NULL, "gv_linear_timing_read: null rows");
+    Timing& tm = timing();
+    std::lock_guard<std::mutex> lk(tm.mu);
+    int n = 0;
+    for (auto& r : tm.recs) {
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e != hipSuccess) { gv_set_error("gv_linear_timing_read: %s", hipGetErrorString(e)); return (int)e; }
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (e != hipSuccess) { gv_set_error("gv_linear_timing_read: %s", hipGetErrorString(e)); return (int)e; }
+        int i = 0;
+        while (i < n && rows[i].key != r.key) ++i;
+        if (i == n) {
+            if (n == max_rows) continue;
+            rows[n] = gv_linear_timing_row{r.key, r.key & 1, (r.key >> 1) & 1, (r.key >> 2) & 1, (r.key >> 3) & 1,
+                                           ((r.key >> 4) & 0xFF) == 0xFF ? -1 : ((r.key >> 4) & 0xFF), 0, 0.0, 0.0};
+            ++n;
+        }
+        rows[i].launches += 1; rows[i].seconds += ms * 1e-3; rows[i].flops += r.flops;
+    }
+    return n;
+}
 
 extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     GV_REQUIRE(a && a->A && a->B && a->C, GV_E_NULL, "gv_linear: null operand");
@@ -158,7 +233,7 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     // specialised epilogue masks of the hot path; anything else (and any N % 4 != 0) runs the
     // runtime-mask build
     const bool generic = (a->N & 7) != 0;
-    constexpr int E_B = GV_EPI_BIAS, E_BGS = GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE, E_BR = GV_EPI_BIAS | GV_EPI_RESID,
+    constexpr int E_B = GV_EPI_BIAS, E_BGS = GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE, E_BG = GV_EPI_BIAS | GV_EPI_GELU, E_BR = GV_EPI_BIAS | GV_EPI_RESID,
                   E_BP = GV_EPI_BIAS | GV_EPI_POS, E_DG = GV_EPI_DGELU, E_ACC = GV_EPI_ACCUM;
     if (ta && tb) {
         if (p.ksplit > 1 && !generic) return finish(launch<true, true, float, true, E_ACC>(p, s));
@@ -187,5 +262,6 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     if (!generic && e == 0) return launch<false, false, bf16, false, 0>(p, s);
     if (!generic && e == E_B) return launch<false, false, bf16, false, E_B>(p, s);
     if (!generic && e == E_BGS) return launch<false, false, bf16, false, E_BGS>(p, s);
+    if (!generic && e == E_BG) return launch<false, false, bf16, false, E_BG>(p, s);
     return launch<false, false, bf16, false>(p, s);
 }

@@ -23,9 +23,11 @@ struct GemmP {
 };
 
 // BM x BN output tile, BK reduction depth per ring stage, WM x WN waves, NSTAGE ring stages
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_>
+// SCHED: where the next stage's LDS-DMA pieces are issued inside a k-step --
+//   0 before the fragment reads, 1 after the reads, 2 between the MFMA k-halves, 3 one piece per MFMA row group
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int SCHED_ = 0>
 struct Cfg {
-    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_;
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, SCHED = SCHED_;
     static constexpr int NW = WM * WN, THREADS = NW * 64;
     static constexpr int FM = BM / WM / 16, FN = BN / WN / 16;      // 16x16 fragments per wave
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -96,15 +98,16 @@ struct TileSrc {
             }
         }
     }
-    // issue this wave's pieces of the k-step starting at reduction index k0
+    // issue piece p of this wave's share of the k-step starting at reduction index k0
+    __device__ __forceinline__ void issue_one(int p, long ld, int k0, int klim, GV_LDS char* tile, int wave) const {
+        const bf16* src;
+        if constexpr (!T) src = ptr[p] + k0;
+        else src = (ok[p] && k0 + r[p] < klim) ? ptr[p] + (long)k0 * ld : (const bf16*)zero_page;
+        glds16(src, tile + (wave * PPW + p) * 1024);
+    }
     __device__ __forceinline__ void issue(long ld, int k0, int klim, GV_LDS char* tile, int wave) const {
 #pragma unroll
-        for (int p = 0; p < PPW; ++p) {
-            const bf16* src;
-            if constexpr (!T) src = ptr[p] + k0;
-            else src = (ok[p] && k0 + r[p] < klim) ? ptr[p] + (long)k0 * ld : (const bf16*)zero_page;
-            glds16(src, tile + (wave * PPW + p) * 1024);
-        }
+        for (int p = 0; p < PPW; ++p) issue_one(p, ld, k0, klim, tile, wave);
     }
 };
 
@@ -237,6 +240,19 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             ++l_k;
             l_stage = (l_stage + 1 == NSTAGE) ? 0 : l_stage + 1;
         };
+        // the same, one piece at a time (SCHED >= 2 spreads a step's pieces between its MFMAs)
+        bool p_live = false; GV_LDS char* p_st = smem; int p_k0 = 0;
+        auto issue_begin = [&]() {
+            p_live = l_k < it.nt && !(g.epi & (1 << 21));
+            p_st = smem + l_stage * C::STAGE; p_k0 = it.kbeg + l_k * BK;
+            ++l_k;
+            l_stage = (l_stage + 1 == NSTAGE) ? 0 : l_stage + 1;
+        };
+        auto issue_piece = [&](int p) {
+            if (!p_live) return;
+            if (p < C::A_PPW) srcA.issue_one(p, g.lda, p_k0, it.kend, p_st, wave);
+            else srcB.issue_one(p - C::A_PPW, g.ldb, p_k0, it.kend, p_st + C::A_BYTES, wave);
+        };
 #pragma unroll
         for (int s = 0; s < PD; ++s) issue();
 
@@ -325,7 +341,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             GV_STAMP(ts1);
             __builtin_amdgcn_s_barrier();     // everybody's pieces landed; last step's stage is free
             GV_STAMP(ts2);
-            issue();
+            if constexpr (C::SCHED == 0) issue();
             GV_STAMP(ts3);
             GV_LDS char* cur = smem + c_stage * C::STAGE;
             // all fragment reads of the stage are issued up front (KS * (FM + FN) ds_read_b128 /
@@ -351,13 +367,33 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
 #ifdef GV_GEMM_PIN_READS
             __builtin_amdgcn_sched_barrier(0);   // keep every read ahead of the first MFMA
 #endif
+            if constexpr (C::SCHED == 1) issue();
+            if constexpr (C::SCHED >= 2) issue_begin();
+            constexpr int GROUPS = C::KS * FM;                     // MFMA row groups of FN MFMAs each
+            constexpr int PER = (C::GLDS + GROUPS - 1) / GROUPS;   // SCHED 3: pieces per group
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks)
+            for (int ks = 0; ks < C::KS; ++ks) {
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                    if constexpr (C::SCHED == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < PER; ++q) { const int pc = (ks * FM + i) * PER + q; if (pc < C::GLDS) issue_piece(pc); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (C::SCHED == 2) {
+                    if (ks == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int pc = 0; pc < C::GLDS; ++pc) issue_piece(pc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
             if constexpr (TA) {
                 if (do_colsum) {
 #pragma unroll

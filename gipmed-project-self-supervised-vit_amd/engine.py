@@ -273,8 +273,9 @@ class VitRunner:
             ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
                        bias=W.f(b + "attn.proj.bias"), resid=xa)
             ops.layernorm_fwd(xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), T, D, y=G.xn2[s], mean=st[2], rstd=st[3])
-            ops.linear(G.xn2[s], W.w(b + "mlp.fc1.weight"), G.h[s], T, 4 * D, D, epilogue=E.EPI_BIAS | E.EPI_GELU | E.EPI_SAVE_PRE,
-                       bias=W.f(b + "mlp.fc1.bias"), aux_out=G.hp[s])
+            ops.linear(G.xn2[s], W.w(b + "mlp.fc1.weight"), G.h[s], T, 4 * D, D,
+                       epilogue=E.EPI_BIAS | E.EPI_GELU | (E.EPI_SAVE_PRE if G.save else 0),   # a forward-only group keeps no pre-activation
+                       bias=W.f(b + "mlp.fc1.bias"), aux_out=G.hp[s] if G.save else None)
             ops.linear(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
                        bias=W.f(b + "mlp.fc2.bias"), resid=xb)
         xl = G.xbuf(2 * self.depth)

@@ -103,6 +103,27 @@ def linear(A, B, C, M: int, N: int, K: int, *, trans_a=False, trans_b=False, epi
     return C
 
 
+def linear_timing(enable: bool):
+    """Start (True) / stop (False) HIP-event timing of every GEMM launch inside gv_linear."""
+    rc = L.lib.gv_linear_timing(int(enable))
+    if rc != 0:
+        raise L.GipvitError(f"gv_linear_timing: {rc}")
+
+
+def linear_timing_read():
+    """Rows {kernel, launches, seconds, flops} per GEMM kernel instantiation since linear_timing(True)."""
+    rows = (L.gv_linear_timing_row * 64)()
+    n = L.lib.gv_linear_timing_read(rows, 64)
+    if n < 0 or n > 64:
+        raise L.GipvitError(f"gv_linear_timing_read: {n}: {L.lib.gv_last_error().decode()}")
+    out = []
+    for r in rows[:n]:
+        name = (f"gemm_kernel<{'true' if r.trans_a else 'false'}, {'true' if r.trans_b else 'false'}, "
+                f"{'float' if r.c_is_f32 else 'bf16'}, {'true' if r.splitk else 'false'}, {r.epilogue}>")
+        out.append({"kernel": name, "launches": r.launches, "seconds": r.seconds, "flops": r.flops})
+    return out
+
+
 def attention_fwd(qkv, n_img: int, N: int, H: int, scale: float, o=None, lse=None):
     dev = qkv.device
     o = torch.empty(n_img * N, H * 64, dtype=bf16, device=dev) if o is None else o

@@ -160,6 +160,19 @@ typedef struct {
 int64_t gv_linear_workspace_bytes(void);
 int gv_linear(const gv_linear_args* a, void* stream);
 
+/* Live per-kernel timing of gv_linear's GEMM launches (bench.py's roofline leg): while enabled,
+ * every GEMM launch is bracketed by two HIP events on the launch stream.  gv_linear_timing(1)
+ * clears earlier records and starts recording, gv_linear_timing(0) stops.  _read synchronises
+ * on the recorded events and folds them into one row per kernel instantiation
+ * gemm_kernel<trans_a, trans_b, c_is_f32 ? float : bf16, splitk, epilogue> (epilogue -1 = the
+ * runtime-mask build); returns the number of rows written (<= max_rows) or an error.        */
+typedef struct {
+    int32_t key, trans_a, trans_b, c_is_f32, splitk, epilogue, launches;
+    double seconds, flops;   /* summed over the launches */
+} gv_linear_timing_row;
+int gv_linear_timing(int enable);
+int gv_linear_timing_read(gv_linear_timing_row* rows, int max_rows);
+
 /* ---- attention (vit.pyc@L119-131): softmax(q k^T * scale) v per (image, head)
  * on packed qkv bf16 [n_img*N, 3, H, 64] -> o bf16 [n_img*N, H, 64];
  * lse f32 [n_img, H, N] (natural-log sum-exp of the scaled scores).

@@ -66,7 +66,7 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
         p.pos = resid;   // stamp sink (lab shapes never use POS); resid doubles as scratch here
 #endif
         float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
-        for (int v = 0; v < 4; ++v) {      // 0 full, 1 no-store, 2 no-store+no-global-load, 3 no-store+no-LDS-read
+        for (int v = 0; v < (getenv("LAB_FULL_ONLY") ? 1 : 4); ++v) {      // 0 full, 1 no-store, 2 no-store+no-global-load, 3 no-store+no-LDS-read
             const int pm = 0, order = 0; p.epi = sh.epi | (v >= 1 ? (1 << 20) : 0) | (v == 2 ? (1 << 21) : 0) | (v == 3 ? (1 << 22) : 0);
             for (int round = 0; round < 3; ++round) {
                 float t;
@@ -92,21 +92,20 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
 
 int main(int argc, char** argv) {
     const int only_cfg = argc > 1 ? atoi(argv[1]) : -1, only_shape = argc > 2 ? atoi(argv[2]) : -1;
-    const int T = 25216;
+    const int T = getenv("LAB_T") ? atoi(getenv("LAB_T")) : 25216;
     std::vector<Shape> all_shapes = {
         {"qkv(NT,bias)", T, 1152, 384, false, false, GV_EPI_BIAS, false},
         {"fc1(NT,b+gelu+pre)", T, 1536, 384, false, false, GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE, false},
+        {"proj(NT,b+res,f32)", T, 384, 384, false, false, GV_EPI_BIAS | GV_EPI_RESID, true},
         {"fc2(NT,b+res,f32)", T, 384, 1536, false, false, GV_EPI_BIAS | GV_EPI_RESID, true},
         {"dX fc1(NN)", T, 384, 1536, false, true, 0, false},
+        {"dX qkv(NN)", T, 384, 1152, false, true, 0, false},
+        {"dX proj(NN)", T, 384, 384, false, true, 0, false},
         {"dX fc2(NN)", T, 1536, 384, false, true, 0, false},
-        {"dW fc1(TN,noSplit)", 1536, 384, T, true, true, 0, true},
-        {"dW~split7 (TN)", 1536, 2688, 3602, true, true, 0, true},
-        {"dW~split4 (TN)", 1536, 1536, 6304, true, true, 0, true},
-        {"dW~split14 (TN)", 1536, 5376, 1801, true, true, 0, true},
     };
     std::vector<Shape> shapes;
     for (int i = 0; i < (int)all_shapes.size(); ++i) if (only_shape < 0 || only_shape == i) shapes.push_back(all_shapes[i]);
-    size_t nA = (size_t)T * 1536, nB = (size_t)1536 * T, nC = (size_t)T * 1536;
+    size_t nA = (size_t)T * 1536 + 4096, nB = (size_t)1536 * T, nC = (size_t)T * 1536;
     std::vector<unsigned short> hA(nA), hB(nB);
     srand(1);
     for (auto& x : hA) x = f2bf((rand() / (float)RAND_MAX - 0.5f));
@@ -116,18 +115,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&bias, 4096 * 4)); CK(hipMalloc(&resid, nC * 4));
     CK(hipMemcpy(A, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), nB * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, 4096 * 4)); CK(hipMemset(resid, 0, nC * 4)); CK(hipMemset(aux, 0, nC * 2));
-    //            BM   BN  BK WM WN NSTAGE
-    if (only_cfg < 0 || only_cfg == 10) run_all<Cfg<128, 128, 32, 2, 2, 2>>("128x128 k32 2x2 s2 w4", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 11) run_all<Cfg<128, 64, 64, 2, 2, 2>>("128x64 k64 2x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 0) run_all<Cfg<128, 128, 32, 2, 2, 4>>("128x128 k32 2x2 s4", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 1) run_all<Cfg<128, 128, 64, 2, 2, 2>>("128x128 k64 2x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 2) run_all<Cfg<128, 128, 64, 2, 2, 3>>("128x128 k64 2x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 3) run_all<Cfg<256, 128, 32, 4, 2, 3>>("256x128 k32 4x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 4) run_all<Cfg<256, 128, 32, 2, 2, 3>>("256x128 k32 2x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 5) run_all<Cfg<256, 128, 64, 4, 2, 2>>("256x128 k64 4x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 6) run_all<Cfg<256, 128, 64, 4, 2, 3>>("256x128 k64 4x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 7) run_all<Cfg<256, 256, 32, 4, 2, 3>>("256x256 k32 4x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 8) run_all<Cfg<256, 256, 64, 4, 2, 2>>("256x256 k64 4x2 s2", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 9) run_all<Cfg<128, 256, 32, 2, 2, 3>>("128x256 k32 2x2 s3", shapes, A, B, C, nullptr, bias, aux, resid);
+    //            BM   BN  BK WM WN NSTAGE SCHED
+    if (only_cfg < 0 || only_cfg == 0) run_all<Cfg<128, 128, 64, 2, 2, 2, 0>>("128x128", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 1) run_all<Cfg<96, 128, 64, 2, 2, 2, 0>>("96x128", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 2) run_all<Cfg<64, 128, 64, 2, 2, 2, 0>>("64x128", shapes, A, B, C, nullptr, bias, aux, resid);
     return 0;
 }
