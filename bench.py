@@ -135,13 +135,13 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.arch}/16 DINO 2x224+{n_local}x96 crops of 256px NHWC u8 tiles, K=65536 ({args.config})",
                        "tiles_per_gpu": args.batch, "global_tiles": args.batch * world, "parallelism": f"dp{world}",
-                       "hipgraph": use_graph},
+                       "hipgraph": use_graph, "side_stream": eng.vit.side is not None},
             "tiles_per_s_per_gpu": round(tiles_s / world, 2),
             "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[args.config] / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
             if args.arch == "vit_small" else None,
             "final_loss": round(loss, 4),
         }
-        out["roofline"] = roofline.dominant_kernel_roofline(lambda: eng.step(tiles), steps=3) if world == 1 else None
+        out["roofline"] = roofline.dominant_kernel_roofline(lambda: eng.step(tiles), steps=3, vit=eng.vit) if world == 1 else None
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch, n_local)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -20,6 +20,7 @@ can be captured in a hipGraph (``capture=True``).
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -219,7 +220,7 @@ class VitGroup:
         self.h = [e((T, 4 * D), bf16) for _ in range(nb)]
         self.stats = [[e((T,), f32) for _ in range(4)] for _ in range(nb)]   # mean1, rstd1, mean2, rstd2
         if save:   # backward scratch
-            self.g, self.gb = e((T, D), f32), e((T, D), bf16)
+            self.g, self.gb, self.gb2 = e((T, D), f32), e((T, D), bf16), e((T, D), bf16)
             self.dh = e((T, 4 * D), bf16)
             self.dxn = e((T, D), bf16)
             self.dqkv = e((T, 3 * D), bf16)
@@ -241,6 +242,9 @@ class VitRunner:
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
         self.one = torch.ones(1, dtype=f32, device=device)
         self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
+        cuda = torch.device(device).type == "cuda"
+        self.side = torch.cuda.Stream(device) if cuda and os.environ.get("GIPVIT_DW_STREAM", "1") != "0" else None
+        self._events: List[torch.cuda.Event] = []
 
     # ---- forward: tiles -> CLS features written into feats[row_off + seg.img0 ...]
     def forward(self, W: Weights, G: VitGroup, tiles_u8, windows, mean, std, feats, row_off: int = 0):
@@ -300,28 +304,72 @@ class VitRunner:
             ops.layernorm_bwd(dfeat[sg.img0:sg.img0 + sg.n_img], sg.rows(xl), sg.fstats[0], sg.fstats[1], W.f("norm.weight"), sg.rows(G.g),
                               sg.rows(G.gb), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True)
             self._fin3(W.g("norm.weight"), W.g("norm.bias"), W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
+        # The weight-gradient GEMMs are off the critical path (nothing in backward consumes dW):
+        # they run on a side stream beside the dX chain, so their tiles fill the tail of every
+        # main-stream kernel (a 345 x 3-tile GEMM occupies 2.02 rounds of the 512 workgroup slots).
+        # fork(): side waits for what main has enqueued; join(ev): main waits for a side event
+        # before it overwrites a buffer a dW product still reads (gb / dh / dqkv).
+        main = torch.cuda.current_stream() if xl.is_cuda else None
+        side = self.side if (main is not None and self.side is not None and not torch.cuda.is_current_stream_capturing()) else None
+        evs = self._events
+        n_ev = [0]
+
+        def new_event():
+            if n_ev[0] == len(evs):
+                evs.append(torch.cuda.Event())
+            n_ev[0] += 1
+            return evs[n_ev[0] - 1]
+
+        def dw(A, Bm, Cg, M, N, colsum_a=None):
+            """dW (+)= A^T Bm on the side stream once main's work so far is done; returns the event that marks its end."""
+            if side is None:
+                ops.linear(A, Bm, Cg, M, N, T, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=colsum_a, workspace=self.ws)
+                return None
+            e0 = new_event(); e0.record(main); side.wait_event(e0)
+            with torch.cuda.stream(side):
+                ops.linear(A, Bm, Cg, M, N, T, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=colsum_a, workspace=self.ws)
+                e1 = new_event(); e1.record(side)
+            return e1
+
+        def join(ev):
+            if ev is not None:
+                main.wait_event(ev)
+
+        gbs = (G.gb, G.gb2)              # gb: dY of the MLP half, gb2: dY of the attention half
+        done_fc1 = done_qkv = done_fc2 = done_proj = None
+        pending_block = None
         for i in reversed(range(self.depth)):
             b, st = f"blocks.{i}.", G.stats[i]
             # MLP
-            ops.linear(G.gb, W.w(b + "mlp.fc2.weight"), G.dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
-            ops.linear(G.gb, G.h[i], W.g(b + "mlp.fc2.weight"), D, 4 * D, T, trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
+            join(done_fc1)               # last block's dW_fc1 read dh
+            ops.linear(gbs[0], W.w(b + "mlp.fc2.weight"), G.dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
+            done_fc2 = dw(gbs[0], G.h[i], W.g(b + "mlp.fc2.weight"), D, 4 * D)
             ops.linear(G.dh, W.w(b + "mlp.fc1.weight"), G.dxn, T, D, 4 * D, trans_b=True)
-            ops.linear(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC,
-                       colsum_a=W.g(b + "mlp.fc1.bias"), workspace=self.ws)
-            ops.layernorm_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), G.g, G.gb, self.partials, T, D)
+            done_fc1 = dw(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, colsum_a=W.g(b + "mlp.fc1.bias"))
+            join(done_proj)              # last block's dW_proj read gb2
+            ops.layernorm_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), G.g, gbs[1], self.partials, T, D)
             self._fin3(W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"))
             # attention
-            ops.linear(G.gb, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
-            ops.linear(G.gb, G.o[i], W.g(b + "attn.proj.weight"), D, D, T, trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
+            ops.linear(gbs[1], W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
+            done_proj = dw(gbs[1], G.o[i], W.g(b + "attn.proj.weight"), D, D)
+            join(done_qkv)               # last block's dW_qkv read dqkv
             for sg in G.segs:
                 ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(G.dqkv))
             ops.linear(G.dqkv, W.w(b + "attn.qkv.weight"), G.dxn, T, D, 3 * D, trans_b=True)
-            ops.linear(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, T, trans_a=True, trans_b=True, epilogue=ACC,
-                       colsum_a=W.g(b + "attn.qkv.bias"), workspace=self.ws)
-            ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, G.gb, self.partials, T, D)
+            done_qkv = dw(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, colsum_a=W.g(b + "attn.qkv.bias"))
+            join(done_fc2)               # this block's dW_fc2 read gb
+            ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, gbs[0], self.partials, T, D)
             self._fin3(W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
             if on_block_done is not None:
-                on_block_done(i)
+                if side is None:
+                    on_block_done(i)
+                else:           # block i's dW products are still running beside us: report the block one iteration later
+                    if pending_block is not None:
+                        join(pending_block[1]); on_block_done(pending_block[0])
+                    pending_block = (i, done_qkv)
+        join(done_qkv)          # every dW product is in (the side stream runs them in order); ws is free again
+        if pending_block is not None:
+            on_block_done(pending_block[0])
         # token assembly + patch embedding, per segment
         gpos = W.g("pos_embed").view(-1, D)
         for sg in G.segs:
@@ -453,6 +501,8 @@ class DinoEngine:
         self.train_last_layer = True
         self.t = 0
         self.reducer = reducer if reducer is not None else NoReducer()
+        if torch.device(device).type == "cuda":
+            self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         self.graph = None
         self._static_tiles = None
         # contiguous arena range of every block's weight-decayed matrices (arena order = backward order)
@@ -513,10 +563,23 @@ class DinoEngine:
         B, G, V = self.B, self.G, self.V
         a = self.arena
         a.g.zero_()
-        self.vit.forward(self.tW, self.g_teach, tiles_u8, [self.gwins], self.mean, self.std, self.hb_t.feats)
-        self.head.forward(self.tH, self.wn_t, self.hb_t)
+        # the teacher's forward shares nothing with the student's until the loss: it runs on the
+        # side stream beside the student forward (fills the tail of each other's kernels)
+        side = self.vit.side if (tiles_u8.is_cuda and not torch.cuda.is_current_stream_capturing()) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            self._ev_fork.record(main); side.wait_event(self._ev_fork)
+            with torch.cuda.stream(side):
+                self.vit.forward(self.tW, self.g_teach, tiles_u8, [self.gwins], self.mean, self.std, self.hb_t.feats)
+                self.head.forward(self.tH, self.wn_t, self.hb_t)
+                self._ev_join.record(side)
+        else:
+            self.vit.forward(self.tW, self.g_teach, tiles_u8, [self.gwins], self.mean, self.std, self.hb_t.feats)
+            self.head.forward(self.tH, self.wn_t, self.hb_t)
         self.vit.forward(self.sW, self.g_stu, tiles_u8, self.s_wins, self.mean, self.std, self.hb_s.feats)
         self.head.forward(self.sH, self.wn_s, self.hb_s)
+        if side is not None:
+            main.wait_event(self._ev_join)
         ops.dino_loss(self.hb_s.logits, self.hb_t.logits, self.center, self.hb_s.dlogits, self.loss, self.center_sum,
                       self.loss_ws, B, V, G, self.K, self.ts, self.tt, hyper=self.hyper)
         self.reducer.reduce_tensor(self.center_sum)
