@@ -204,7 +204,8 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
         const int tiles = p.tiles_m * p.tiles_n;
         const bool only_accum = a->c_is_f32 && e == GV_EPI_ACCUM;
         if (only_accum && tiles < 384 && (a->N & 7) == 0) {
-            const int want = (512 + tiles - 1) / tiles;
+            // at most 512 workgroups (2 per CU are resident): one more would run a second round alone
+            const int want = 512 / tiles > 0 ? 512 / tiles : 1;
             const int ksteps = (a->K + BK - 1) / BK;
             const int min_steps = 512 / BK;
             const int maxs = ksteps / min_steps > 0 ? ksteps / min_steps : 1;   // at least 512 deep per slice
