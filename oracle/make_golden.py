@@ -16,8 +16,8 @@ from . import step_oracle as so, vit_oracle as vo
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
-def supervised_c1(steps=20):
-    """BASELINE config 1: ViT-T/16, 64x64, supervised head, B=8, AdamW lr 1e-4 (loss curve)."""
+def supervised_c1(steps=100):
+    """BASELINE config 1: ViT-T/16, 64x64, supervised head, B=8, AdamW lr 1e-4 (100-step loss curve: the length north_star gates at 1e-3)."""
     orc = so.SupervisedOracle(arch="vit_tiny", img_size=64, num_classes=2, seed=0, lr=1e-4, wd=0.05)
     tiles = vo.synth_tiles(8, 64, seed=1234)
     tgt = torch.randint(0, 2, (8, 1), generator=torch.Generator().manual_seed(5))
