@@ -501,6 +501,7 @@ class DinoEngine:
         self.train_last_layer = True
         self.t = 0
         self.reducer = reducer if reducer is not None else NoReducer()
+        self._n_micro = 1
         if torch.device(device).type == "cuda":
             self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         self.graph = None
@@ -540,7 +541,7 @@ class DinoEngine:
         return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
 
     # ---- the step --------------------------------------------------------------------
-    def set_hyper(self, lr=None, wd=None, momentum_teacher=None, teacher_temp=None):
+    def set_hyper(self, lr=None, wd=None, momentum_teacher=None, teacher_temp=None, n_micro: int = 1):
         """Put the per-step schedule values into the device hyper vector with a tiny stream-ordered
         kernel whose ARGUMENTS carry them (outside any captured graph).  Not a memcpy: the host
         runs many graph replays ahead of the GPU, and a pinned staging buffer would be rewritten
@@ -552,17 +553,22 @@ class DinoEngine:
         vals[L.HYP_BC1] = 1.0 - self.betas[0] ** self.t
         vals[L.HYP_BC2] = 1.0 - self.betas[1] ** self.t
         vals[L.HYP_TEACHER_MOM] = self.m_teacher if momentum_teacher is None else momentum_teacher
-        vals[L.HYP_GRAD_SCALE] = 1.0 / self.reducer.world
+        vals[L.HYP_GRAD_SCALE] = 1.0 / (self.reducer.world * n_micro)
         vals[L.HYP_TEACHER_TEMP] = self.tt if teacher_temp is None else teacher_temp
         vals[L.HYP_STUDENT_TEMP] = self.ts
         ops.store_f32(self.hyper, vals)
 
-    def forward_backward(self, tiles_u8: torch.Tensor):
+    def forward_backward(self, tiles_u8: torch.Tensor, micro: Tuple[int, int] = (0, 1)):
         """teacher fwd (global crops) -> student fwd (all crops) -> loss -> backward.
-        Leaves un-reduced gradients in arena.g, loss in self.loss, center_sum."""
+        Leaves gradients in arena.g, loss in self.loss, center_sum.  ``micro = (j, n)``: this is
+        micro-batch j of n (gradient accumulation): gradients, loss and centre sums add up over
+        the n calls and the data-parallel reduction is issued from the last one only."""
         B, G, V = self.B, self.G, self.V
         a = self.arena
-        a.g.zero_()
+        mj, mn = micro
+        first, last = mj == 0, mj == mn - 1
+        if first:
+            a.g.zero_()
         # the teacher's forward shares nothing with the student's until the loss: it runs on the
         # side stream beside the student forward (fills the tail of each other's kernels)
         side = self.vit.side if (tiles_u8.is_cuda and not torch.cuda.is_current_stream_capturing()) else None
@@ -582,8 +588,19 @@ class DinoEngine:
             main.wait_event(self._ev_join)
         ops.dino_loss(self.hb_s.logits, self.hb_t.logits, self.center, self.hb_s.dlogits, self.loss, self.center_sum,
                       self.loss_ws, B, V, G, self.K, self.ts, self.tt, hyper=self.hyper)
-        self.reducer.reduce_tensor(self.center_sum)
+        if mn > 1:
+            if first:
+                self._loss_acc, self._center_acc = self.loss.clone(), self.center_sum.clone()
+            else:
+                self._loss_acc += self.loss; self._center_acc += self.center_sum
+            if last:
+                self.loss.copy_(self._loss_acc / mn); self.center_sum.copy_(self._center_acc)
+        if last:
+            self.reducer.reduce_tensor(self.center_sum)
         self.head.backward(self.sH, self.wn_s, self.hb_s, self.train_last_layer)
+        if not last:        # more micro-batches follow: gradients keep accumulating locally
+            self.vit.backward(self.sW, self.g_stu, self.hb_s.dfeats)
+            return
         # head gradients are final: start their reduction while the backbone runs backward
         head_names = [n for n in a.order if n.startswith("head.") and a.off[n] < a.n_decay]
         if head_names:
@@ -619,7 +636,23 @@ class DinoEngine:
             sl = slice(a.n_decay, a.n)
             ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], a.t[sl], a.tb[sl], a.n - a.n_decay, weight_decay=0.0, **kw)
         self._refresh_wn()
-        ops.center_update(self.center, self.center_sum, self.K, self.cm, 1.0 / (self.G * self.B * self.reducer.world))
+        ops.center_update(self.center, self.center_sum, self.K, self.cm, 1.0 / (self.G * self.B * self.reducer.world * self._n_micro))
+
+    def step_micro(self, tile_batches: Sequence[torch.Tensor], **sched) -> torch.Tensor:
+        """One optimizer step over ``len(tile_batches)`` micro-batches of B tiles each (gradient
+        accumulation; BASELINE config 5 reaches 512 tiles per GPU this way).  Equals ``step`` on the
+        concatenated batch up to summation order."""
+        n = len(tile_batches)
+        self.set_hyper(n_micro=n, **sched)
+        for j, tb in enumerate(tile_batches):
+            assert tb.shape == (self.B, self.tile, self.tile, 3) and tb.dtype == torch.uint8
+            self.forward_backward(tb, micro=(j, n))
+        self._n_micro = n
+        try:
+            self.optimizer_step()
+        finally:
+            self._n_micro = 1
+        return self.loss
 
     def step(self, tiles_u8: torch.Tensor, **sched) -> torch.Tensor:
         """One full training step on [B, tile, tile, 3] uint8 NHWC tiles.  Returns the
