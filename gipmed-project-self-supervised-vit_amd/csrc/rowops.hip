@@ -12,22 +12,25 @@ __global__ void cls_rows_kernel(gv_cls_rows_args a) {
         a.x[(long)i * a.N * a.D + d] = a.cls[d] + a.pos[d];
 }
 
-// grid (N tokens, D/256): each thread sums one (token, column) over the images;
-// patch rows are also re-emitted compact in bf16.
+// grid (N tokens, D/256, image chunks): each thread sums one (token, column) over its chunk of
+// images and adds the partial into dpos with one f32 atomic (dpos is zeroed by the entry point
+// unless it accumulates); patch rows are also re-emitted compact in bf16.
+constexpr int TOK_IMG_PER_CHUNK = 8;
 __global__ void tokens_bwd_kernel(gv_tokens_bwd_args a) {
     const int t = blockIdx.x;
     const int d = blockIdx.y * blockDim.x + threadIdx.x;
     if (d >= a.D) return;
     const int P = a.N - 1;
+    const int i0 = blockIdx.z * TOK_IMG_PER_CHUNK, i1 = min(a.n_img, i0 + TOK_IMG_PER_CHUNK);
     float s = 0.f;
-    for (int i = 0; i < a.n_img; ++i) {
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
         const float v = a.g[((long)i * a.N + t) * a.D + d];
         s += v;
         if (t > 0) ((bf16*)a.gpatch)[((long)i * P + (t - 1)) * a.D + d] = (bf16)v;
     }
-    float* o = a.dpos + (long)t * a.D + d;
-    *o = a.accumulate ? *o + s : s;
-    if (t == 0 && a.dcls) a.dcls[d] = a.accumulate ? a.dcls[d] + s : s;
+    atomicAdd(a.dpos + (long)t * a.D + d, s);
+    if (t == 0 && a.dcls) atomicAdd(a.dcls + d, s);
 }
 
 __global__ void small_matmul_kernel(gv_small_matmul_args a) {
@@ -232,7 +235,13 @@ extern "C" int gv_cls_rows(const gv_cls_rows_args* a, void* stream) {
 extern "C" int gv_tokens_bwd(const gv_tokens_bwd_args* a, void* stream) {
     GV_REQUIRE(a && a->g && a->gpatch && a->dpos, GV_E_NULL, "gv_tokens_bwd: null pointer");
     GV_REQUIRE(a->n_img > 0 && a->N > 1 && a->D > 0, GV_E_SHAPE, "gv_tokens_bwd: bad shape");
-    hipLaunchKernelGGL(tokens_bwd_kernel, dim3(a->N, (a->D + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    if (!a->accumulate) {
+        hipError_t e = hipMemsetAsync(a->dpos, 0, (size_t)a->N * a->D * sizeof(float), (hipStream_t)stream);
+        if (e == hipSuccess && a->dcls) e = hipMemsetAsync(a->dcls, 0, (size_t)a->D * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) { gv_set_error("gv_tokens_bwd: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    hipLaunchKernelGGL(tokens_bwd_kernel, dim3(a->N, (a->D + 255) / 256, (a->n_img + TOK_IMG_PER_CHUNK - 1) / TOK_IMG_PER_CHUNK), dim3(256), 0,
+                       (hipStream_t)stream, *a);
     GV_LAUNCH_CHECK("gv_tokens_bwd");
     return GV_OK;
 }

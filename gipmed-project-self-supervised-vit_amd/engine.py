@@ -337,7 +337,6 @@ class VitRunner:
 
         gbs = (G.gb, G.gb2)              # gb: dY of the MLP half, gb2: dY of the attention half
         done_fc1 = done_qkv = done_fc2 = done_proj = None
-        pending_block = None
         for i in reversed(range(self.depth)):
             b, st = f"blocks.{i}.", G.stats[i]
             # MLP
@@ -361,15 +360,14 @@ class VitRunner:
             ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, gbs[0], self.partials, T, D)
             self._fin3(W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
             if on_block_done is not None:
+                # the block's weight gradients are produced by the side stream: report the block from
+                # there, so a data-parallel all-reduce queues behind the dW products and main never waits
                 if side is None:
                     on_block_done(i)
-                else:           # block i's dW products are still running beside us: report the block one iteration later
-                    if pending_block is not None:
-                        join(pending_block[1]); on_block_done(pending_block[0])
-                    pending_block = (i, done_qkv)
+                else:
+                    with torch.cuda.stream(side):
+                        on_block_done(i)
         join(done_qkv)          # every dW product is in (the side stream runs them in order); ws is free again
-        if pending_block is not None:
-            on_block_done(pending_block[0])
         # token assembly + patch embedding, per segment
         gpos = W.g("pos_embed").view(-1, D)
         for sg in G.segs:
@@ -616,7 +614,7 @@ class DinoEngine:
 
         def block_done(i):
             lo, hi = self._block_range[i]
-            if self.reducer.world > 1:
+            if self.reducer.world > 1 or getattr(self.reducer, "always", False):
                 self.reducer.reduce_range(a.g, min(lo, state["hi"]), hi)
                 state["hi"] = hi
 

@@ -22,6 +22,12 @@ probabilities instead of a per-step D2H sync (1054); tiles are sharded over rank
 """
 from __future__ import annotations
 
+import os as _os
+# The step uses three streams with cross-stream waits (main, the side stream of engine.py, RCCL's
+# communication stream).  HIP maps streams onto 4 hardware queues by default and a stream's wait
+# blocks everything behind it in a shared queue: measured 20.2 vs 18.2 ms/step with RCCL in the
+# picture.  Must be set before the HIP runtime initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import csv
 import logging
