@@ -90,7 +90,7 @@ class gv_linear_timing_row(C.Structure):
                 ("epilogue", C.c_int32), ("launches", C.c_int32), ("seconds", C.c_double), ("flops", C.c_double)]
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_POS, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
-LN_PARTIAL_BLOCKS = 512
+LN_PARTIAL_BLOCKS = 1024
 HYP_LR, HYP_WD, HYP_BC1, HYP_BC2, HYP_TEACHER_MOM, HYP_GRAD_SCALE, HYP_TEACHER_TEMP, HYP_STUDENT_TEMP, HYP_COUNT = range(9)
 
 

@@ -36,40 +36,58 @@ template <int VEC> __device__ __forceinline__ void stb(bf16* p, const float* o) 
     *(typename VecB<VEC>::T*)p = v;
 }
 
+// grid-stride over rows, one wave per row; the next row's loads are issued before the current
+// row's reductions so every wave keeps two rows of HBM traffic in flight
 template <int VEC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(gv_layernorm_fwd_args a) {
     constexpr int D = 192 * VEC;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
-    const float* x = a.x + (long)row * a.x_stride;
-    float v[3][VEC];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        ldf<VEC>(x + (i * 64 + lane) * VEC, v[i]);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) s += v[i][j];
-    }
-    const float mean = wave_sum(s) * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { const float d = v[i][j] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + a.eps);
-    bf16* y = (bf16*)a.y + (long)row * D;
+    float gm[3][VEC], bt[3][VEC], v[3][VEC], nv[3][VEC];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int c = (i * 64 + lane) * VEC;
-        float gm[VEC], bt[VEC], o[VEC];
-        ldf<VEC>(a.gamma + c, gm);
-        ldf<VEC>(a.beta + c, bt);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * gm[j] + bt[j];
-        stb<VEC>(y + c, o);
+        ldf<VEC>(a.gamma + c, gm[i]);
+        ldf<VEC>(a.beta + c, bt[i]);
+        ldf<VEC>(a.x + (long)row * a.x_stride + c, v[i]);
     }
-    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    while (true) {
+        const int nrow = row + stride;
+        const bool more = nrow < a.rows;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ldf<VEC>(a.x + (long)nrow * a.x_stride + (i * 64 + lane) * VEC, nv[i]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s += v[i][j];
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + a.eps);
+        bf16* y = (bf16*)a.y + (long)row * D;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j];
+            stb<VEC>(y + (i * 64 + lane) * VEC, o);
+        }
+        if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[i][j] = nv[i][j];
+        row = nrow;
+    }
 }
 
 template <int VEC>
@@ -89,8 +107,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(gv_layernorm_bwd_args a) {
         const bf16* dy = (const bf16*)a.dy + (long)row * D;
         float* g = a.g + (long)row * a.g_stride;
         const float mean = a.mean[row], rstd = a.rstd[row];
-        float xh[3][VEC], wdy[3][VEC];
+        float xh[3][VEC], wdy[3][VEC], gv[3][VEC];
         float c1 = 0.f, c2 = 0.f;
+        // every load of the row is issued before the first reduction (the old residual-gradient
+        // row used to be fetched only after both wave sums: one more exposed HBM round trip per row)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if (a.g_init) { _Pragma("unroll") for (int j = 0; j < VEC; ++j) gv[i][j] = 0.f; }
+            else ldf<VEC>(g + c, gv[i]);
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int c = (i * 64 + lane) * VEC;
@@ -112,16 +138,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(gv_layernorm_bwd_args a) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int c = (i * 64 + lane) * VEC;
-            float gv[VEC];
-            if (a.g_init) { _Pragma("unroll") for (int j = 0; j < VEC; ++j) gv[j] = 0.f; }
-            else ldf<VEC>(g + c, gv);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                gv[j] += rstd * (wdy[i][j] - c1 - xh[i][j] * c2);
-                s_g[i][j] += gv[j];
+                gv[i][j] += rstd * (wdy[i][j] - c1 - xh[i][j] * c2);
+                s_g[i][j] += gv[i][j];
             }
-            stf<VEC>(g + c, gv);
-            if (a.gb) stb<VEC>((bf16*)a.gb + (long)row * a.gb_stride + c, gv);
+            stf<VEC>(g + c, gv[i]);
+            if (a.gb) stb<VEC>((bf16*)a.gb + (long)row * a.gb_stride + c, gv[i]);
         }
     }
     // block reduce of the three column sums -> partials[block][3][D]
@@ -220,7 +243,8 @@ extern "C" int gv_layernorm_fwd(const gv_layernorm_fwd_args* a, void* stream) {
     GV_REQUIRE(a->D == 192 || a->D == 384 || a->D == 768, GV_E_SHAPE, "gv_layernorm_fwd: D=%d not in {192,384,768}", a->D);
     GV_REQUIRE(a->rows > 0, GV_E_SHAPE, "gv_layernorm_fwd: rows must be > 0");
     GV_REQUIRE(a->x_stride % 4 == 0 && gv_aligned(a->x, 16) && gv_aligned(a->y, 8), GV_E_ALIGN, "gv_layernorm_fwd: misaligned");
-    dim3 grid((a->rows + 3) / 4), block(256);
+    const int blocks = (a->rows + 3) / 4;
+    dim3 grid(blocks < 2048 ? blocks : 2048), block(256);     // 8 workgroups (32 waves) per CU, grid-stride over rows
     hipStream_t s = (hipStream_t)stream;
     if (a->D == 192) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, *a);
     else if (a->D == 384) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, *a);

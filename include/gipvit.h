@@ -81,7 +81,7 @@ int gv_layernorm_fwd(const gv_layernorm_fwd_args* a, void* stream);
 /* bwd: g[r] (f32, the residual-stream gradient, stride g_stride) += dLN/dx;
  * gb[r] = bf16(g[r]); partial column sums of dy*xhat, dy and new g are left
  * in `partials` [GV_LN_PARTIAL_BLOCKS, 3, D] f32 for gv_colsum_finalize.   */
-#define GV_LN_PARTIAL_BLOCKS 512
+#define GV_LN_PARTIAL_BLOCKS 1024
 typedef struct {
     const void* dy;       /* bf16 [rows, D] compact                         */
     const float* x; int64_t x_stride;
