@@ -52,7 +52,7 @@ using namespace gvgemm;
 // production geometry (chosen with tools/gemm_lab.hip on MI355X)
 using PCfg = Cfg<GV_GEMM_BM, GV_GEMM_BN, GV_GEMM_BK, GV_GEMM_WM, GV_GEMM_WN, GV_GEMM_NSTAGE>;
 constexpr int BM = PCfg::BM, BN = PCfg::BN, BK = PCfg::BK;
-constexpr int WGS_PER_CU = (160 * 1024 / PCfg::LDS) < 2 ? 1 : 2;
+constexpr int WGS_PER_CU = (160 * 1024 / PCfg::LDS) < 2 ? 1 : ((160 * 1024 / PCfg::LDS) >= 3 ? 3 : 2);
 constexpr int PERSISTENT_GRID = 256 * WGS_PER_CU;
 
 template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI>
@@ -203,9 +203,10 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     {
         const int tiles = p.tiles_m * p.tiles_n;
         const bool only_accum = a->c_is_f32 && e == GV_EPI_ACCUM;
-        if (only_accum && tiles < 384 && (a->N & 7) == 0) {
-            // at most 512 workgroups (2 per CU are resident): one more would run a second round alone
-            const int want = 512 / tiles > 0 ? 512 / tiles : 1;
+        if (only_accum && tiles < 192 * WGS_PER_CU && (a->N & 7) == 0) {
+            // at most as many workgroups as are resident at once: one more would run a second round alone
+            constexpr int SLOTS = 256 * WGS_PER_CU;
+            const int want = SLOTS / tiles > 0 ? SLOTS / tiles : 1;
             const int ksteps = (a->K + BK - 1) / BK;
             const int min_steps = 512 / BK;
             const int maxs = ksteps / min_steps > 0 ? ksteps / min_steps : 1;   // at least 512 deep per slice
