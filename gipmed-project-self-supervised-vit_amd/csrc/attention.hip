@@ -202,13 +202,16 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64) void attn_fwd_kernel(gv_atten
 // backward
 // ---------------------------------------------------------------------------------
 template <int NKT>
-__global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64) void attn_bwd_kernel(gv_attention_bwd_args a, int n_pairs) {
+// short sequences run two 4-wave workgroups per CU: the second launch-bounds argument keeps them within 256 registers
+__global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 2) void attn_bwd_kernel(gv_attention_bwd_args a, int n_pairs) {
     constexpr int NKB = NKT / 2;                       // 32-key blocks = waves per pair
     constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
     constexpr int NW = NKB * PAIRS;                    // waves per workgroup
     constexpr int NP = NKT * 16;
     constexpr int IMG = NP * 128;
-    constexpr int DST = NP * 64;                       // dS^T image: [key][32 q] bf16
+    constexpr int QH = NKT >= 8 ? 2 : 1;               // 32-query halves per barrier pair (short sequences keep 1)
+    constexpr int DROW = 64 * QH;                      // dS^T image: [key][32 QH q] bf16
+    constexpr int DST = NP * DROW;
     constexpr int PER_PAIR = 3 * IMG + DST + 2 * NP * 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GV_LDS char* smem = (GV_LDS char*)smem_raw;
@@ -291,87 +294,95 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64) void attn_bwd_ke
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const int nqc = (N + 31) >> 5;
-    for (int qc = 0; qc < nqc; ++qc) {
-        // ---- phase A: S, dP for [32 q] x [this wave's 32 keys]
-        f32x4 s[2][2], dp[2][2];
+    // 64 queries per barrier pair: phase A runs twice (two 32-query halves, registers as for one) and
+    // fills both halves of the dS^T image, phase B then has 16 dQ tiles to spread over the waves
+    const int nqc2 = (N + 32 * QH - 1) / (32 * QH);
+    for (int qc2 = 0; qc2 < nqc2; ++qc2) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int qrow = qc * 32 + qt * 16 + li;
+        for (int half = 0; half < QH; ++half) {
+            const int qc = qc2 * QH + half;
+            if (qc * 32 >= N) break;
+            // ---- phase A: S, dP for [32 q] x [this wave's 32 keys]
+            f32x4 s[2][2], dp[2][2];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) { s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int qt = 0; qt < 2; ++qt) {
+                const int qrow = qc * 32 + qt * 16 + li;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 qa = read_nat(Qimg, qrow, ks * 4 + g);
-                const bf16x8 da = read_nat(Dimg, qrow, ks * 4 + g);
+                for (int kt = 0; kt < 2; ++kt) { s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    s[qt][kt] = MFMA16(qa, kf[kt][ks], s[qt][kt]);
-                    dp[qt][kt] = MFMA16(da, vf[kt][ks], dp[qt][kt]);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 qa = read_nat(Qimg, qrow, ks * 4 + g);
+                    const bf16x8 da = read_nat(Dimg, qrow, ks * 4 + g);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        s[qt][kt] = MFMA16(qa, kf[kt][ks], s[qt][kt]);
+                        dp[qt][kt] = MFMA16(da, vf[kt][ks], dp[qt][kt]);
+                    }
                 }
             }
-        }
-        // P = exp(scale*S - lse[q]); dS = P * (dP - delta[q]) * scale.  rows q = 4g + r, col key = li
-        f32x4 pv[2][2], ds[2][2];
+            // P = exp(scale*S - lse[q]); dS = P * (dP - delta[q]) * scale.  rows q = 4g + r, col key = li
+            f32x4 pv[2][2], ds[2][2];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int q0 = qc * 32 + qt * 16 + 4 * g;
-            const f32x4 l4 = *(GV_LDS f32x4*)(lse + q0);
-            const f32x4 d4 = *(GV_LDS f32x4*)(delta + q0);
+            for (int qt = 0; qt < 2; ++qt) {
+                const int q0 = qc * 32 + qt * 16 + 4 * g;
+                const f32x4 l4 = *(GV_LDS f32x4*)(lse + q0);
+                const f32x4 d4 = *(GV_LDS f32x4*)(delta + q0);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const bool kok = kb * 32 + kt * 16 + li < N;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = kok && (q0 + r < N);
+                        const float p = ok ? __builtin_amdgcn_exp2f(s[qt][kt][r] * c - l4[r] * 1.4426950408889634f) : 0.f;
+                        pv[qt][kt][r] = p;
+                        ds[qt][kt][r] = p * (dp[qt][kt][r] - d4[r]) * a.scale;
+                    }
+                }
+            }
+            // dV^T += dO^T P ; dK^T += Q^T dS   (reduction over the chunk's 32 queries)
+            {
+                bf16x8 pb[2], sb[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) { pb[kt] = pack8(pv[0][kt], pv[1][kt]); sb[kt] = pack8(ds[0][kt], ds[1][kt]); }
+                const int r0 = qc * 32 + 4 * g + q4;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 dot = cat8(read_tr(Dimg, r0, dt, p4), read_tr(Dimg, r0 + 16, dt, p4));
+                    const bf16x8 qtt = cat8(read_tr(Qimg, r0, dt, p4), read_tr(Qimg, r0 + 16, dt, p4));
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        dv[dt][kt] = MFMA16(dot, pb[kt], dv[dt][kt]);
+                        dk[dt][kt] = MFMA16(qtt, sb[kt], dk[dt][kt]);
+                    }
+                }
+            }
+            // dS^T image [key][32 QH q]: 32-B piece index XOR f(key) (conflict-free transposed reads)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const bool kok = kb * 32 + kt * 16 + li < N;
+                const int key = kb * 32 + kt * 16 + li;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = kok && (q0 + r < N);
-                    const float p = ok ? __builtin_amdgcn_exp2f(s[qt][kt][r] * c - l4[r] * 1.4426950408889634f) : 0.f;
-                    pv[qt][kt][r] = p;
-                    ds[qt][kt][r] = p * (dp[qt][kt][r] - d4[r]) * a.scale;
-                }
+                for (int qt = 0; qt < 2; ++qt)
+                    *(GV_LDS bf16x4*)(dsT + key * DROW + (((half * 2 + qt) ^ (QH == 2 ? (key >> 1) & 3 : (key >> 2) & 1)) << 5) + g * 8) =
+                        bf16x4{(bf16)ds[qt][kt][0], (bf16)ds[qt][kt][1], (bf16)ds[qt][kt][2], (bf16)ds[qt][kt][3]};
             }
-        }
-        // dV^T += dO^T P ; dK^T += Q^T dS   (reduction over the chunk's 32 queries)
-        {
-            bf16x8 pb[2], sb[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) { pb[kt] = pack8(pv[0][kt], pv[1][kt]); sb[kt] = pack8(ds[0][kt], ds[1][kt]); }
-            const int r0 = qc * 32 + 4 * g + q4;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 dot = cat8(read_tr(Dimg, r0, dt, p4), read_tr(Dimg, r0 + 16, dt, p4));
-                const bf16x8 qtt = cat8(read_tr(Qimg, r0, dt, p4), read_tr(Qimg, r0 + 16, dt, p4));
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    dv[dt][kt] = MFMA16(dot, pb[kt], dv[dt][kt]);
-                    dk[dt][kt] = MFMA16(qtt, sb[kt], dk[dt][kt]);
-                }
-            }
-        }
-        // dS^T image [key][32 q]: 64-B rows, 32-B half index XOR ((key >> 2) & 1)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int key = kb * 32 + kt * 16 + li;
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-                *(GV_LDS bf16x4*)(dsT + key * 64 + ((qt ^ ((key >> 2) & 1)) << 5) + g * 8) =
-                    bf16x4{(bf16)ds[qt][kt][0], (bf16)ds[qt][kt][1], (bf16)ds[qt][kt][2], (bf16)ds[qt][kt][3]};
         }
         __syncthreads();
-        // ---- phase B: dQ^T[d][q] = sum_key K[key][d] dS[q][key]; 8 (qt, dt) tiles over the pair's waves
-        for (int tile = kb; tile < 8; tile += NKB) {
+        // ---- phase B: dQ^T[d][q] = sum_key K[key][d] dS[q][key]; 16 (qt, dt) tiles over the pair's waves
+        for (int tile = kb; tile < 8 * QH; tile += NKB) {
             const int qt = tile >> 2, dt = tile & 3;
+            if (qc2 * 32 * QH + qt * 16 >= N) continue;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKB; ++ks) {
                 // k-slot (g, j): key = 32 ks + 16 (j >> 2) + 4 g + (j & 3)
                 const int k0 = ks * 32 + 4 * g + q4;
                 const bf16x8 ka = cat8(read_tr(Kimg, k0, dt, p4), read_tr(Kimg, k0 + 16, dt, p4));
-                const int h0 = qt ^ ((k0 >> 2) & 1), h1 = qt ^ (((k0 + 16) >> 2) & 1);
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(dsT + k0 * 64 + (h0 << 5) + p4 * 8));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(dsT + (k0 + 16) * 64 + (h1 << 5) + p4 * 8));
+                const int hq = qt ^ (QH == 2 ? (k0 >> 1) & 3 : (k0 >> 2) & 1);          // same for key k0 + 16
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(dsT + k0 * DROW + (hq << 5) + p4 * 8));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(dsT + (k0 + 16) * DROW + (hq << 5) + p4 * 8));
                 acc = MFMA16(ka, cat8(lo, hi), acc);
             }
-            const int q = qc * 32 + qt * 16 + li;
+            const int q = qc2 * 32 * QH + qt * 16 + li;
             if (valid && q < N)
                 *(bf16x4*)((bf16*)a.dqkv + ((long)img * N + q) * ld + h * 64 + dt * 16 + 4 * g) =
                     bf16x4{(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
@@ -413,7 +424,7 @@ template <int NKT> int launch_fwd(const gv_attention_fwd_args* a, hipStream_t s)
 
 template <int NKT> int launch_bwd(const gv_attention_bwd_args* a, hipStream_t s) {
     constexpr int NKB = NKT / 2, PAIRS = NKB >= 4 ? 1 : 4 / NKB, NW = NKB * PAIRS, NP = NKT * 16;
-    constexpr int LDS = PAIRS * (3 * NP * 128 + NP * 64 + 2 * NP * 4);
+    constexpr int LDS = PAIRS * (3 * NP * 128 + NP * (NKT >= 8 ? 128 : 64) + 2 * NP * 4);
     auto kern = attn_bwd_kernel<NKT>;
     static bool done = false;
     if (!done) {
