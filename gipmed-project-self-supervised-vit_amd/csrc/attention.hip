@@ -57,7 +57,10 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
 // ---------------------------------------------------------------------------------
 template <int NKT>
 struct FwdCfg {
-    static constexpr int NQB = NKT / 2;                           // 32-query blocks
+    // long sequences: 16 queries per wave and round (the score registers halve, two 8-wave workgroups
+    // fit a CU and cover each other's load phases); short ones: 32 queries per wave
+    static constexpr int QT = NKT >= 14 ? 1 : 2;                  // 16-query tiles per wave and round
+    static constexpr int NQB = (NKT + QT - 1) / QT;               // query blocks of 16 QT rows
     static constexpr int NW = NQB >= 5 ? 8 : 4;                   // waves per workgroup
     static constexpr int PAIRS = NQB >= NW ? 1 : (NW / NQB >= 1 ? NW / NQB : 1);
     static constexpr int WPP = NW / PAIRS;                        // waves per (image, head) pair
@@ -65,9 +68,9 @@ struct FwdCfg {
 };
 
 template <int NKT>
-__global__ __launch_bounds__(FwdCfg<NKT>::NW * 64) void attn_fwd_kernel(gv_attention_fwd_args a, int n_pairs) {
+__global__ __launch_bounds__(FwdCfg<NKT>::NW * 64, FwdCfg<NKT>::QT == 1 ? 2 : 1) void attn_fwd_kernel(gv_attention_fwd_args a, int n_pairs) {
     using F = FwdCfg<NKT>;
-    constexpr int NQB = F::NQB, PAIRS = F::PAIRS, WPP = F::WPP, NW = F::NW, ROUNDS = F::ROUNDS;
+    constexpr int NQB = F::NQB, PAIRS = F::PAIRS, WPP = F::WPP, NW = F::NW, ROUNDS = F::ROUNDS, QT = F::QT, QB = 16 * QT;
     constexpr int NP = NKT * 16;
     constexpr int IMG = NP * 128;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -99,13 +102,13 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64) void attn_fwd_kernel(gv_atten
 
     // this wave's Q fragments for all its query blocks: issued BEFORE the staging wait so the
     // global-load latencies of Q, K and V overlap
-    bf16x8 qf[ROUNDS][2][2];
+    bf16x8 qf[ROUNDS][QT][2];
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int qb = wq + rd * WPP;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            int qrow = qb * 32 + qt * 16 + li;
+        for (int qt = 0; qt < QT; ++qt) {
+            int qrow = qb * QB + qt * 16 + li;
             qrow = qrow < N ? qrow : N - 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) qf[rd][qt][ks] = *(const bf16x8*)(qbase + (long)qrow * ld + ks * 32 + g * 8);
@@ -117,42 +120,44 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64) void attn_fwd_kernel(gv_atten
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int qb = wq + rd * WPP;
-        if (qb >= NQB || qb * 32 >= N) break;
-        f32x4 s[NKT][2];
+        if (qb >= NQB || qb * QB >= N) break;
+        f32x4 s[NKT][QT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-            s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 kf = read_nat(Kimg, kt * 16 + li, ks * 4 + g);
-                s[kt][0] = MFMA16(kf, qf[rd][0][ks], s[kt][0]);
-                s[kt][1] = MFMA16(kf, qf[rd][1][ks], s[kt][1]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) s[kt][qt] = MFMA16(kf, qf[rd][qt][ks], s[kt][qt]);
             }
         }
         // softmax over keys: key = kt*16 + 4g + r lives in (kt, r) of lanes {li, li+16, li+32, li+48}
-        float mx[2] = {-INFINITY, -INFINITY}, sum[2] = {0.f, 0.f};
+        float mx[QT], sum[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) { mx[qt] = -INFINITY; sum[qt] = 0.f; }
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = kt * 16 + 4 * g + r < N;
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     const float v = ok ? s[kt][qt][r] : -INFINITY;
                     s[kt][qt][r] = v;
                     mx[qt] = fmaxf(mx[qt], v);
                 }
             }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
             mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
         }
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f((s[kt][qt][r] - mx[qt]) * c);
@@ -160,30 +165,33 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64) void attn_fwd_kernel(gv_atten
                     sum[qt] += p;
                 }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             sum[qt] += __shfl_xor(sum[qt], 16, 64);
             sum[qt] += __shfl_xor(sum[qt], 32, 64);
         }
         // O^T[d][q] = sum_key V[key][d] P^T[key][q]
-        f32x4 o[4][2];
+        f32x4 o[4][QT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { o[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NKT / 2; ++u) {
-            const bf16x8 pf0 = pack8(s[2 * u][0], s[2 * u + 1][0]);
-            const bf16x8 pf1 = pack8(s[2 * u][1], s[2 * u + 1][1]);
+            bf16x8 pf[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) pf[qt] = pack8(s[2 * u][qt], s[2 * u + 1][qt]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const bf16x8 vf = cat8(read_tr(Vimg, (2 * u) * 16 + 4 * g + q4, dt, p4),
                                        read_tr(Vimg, (2 * u + 1) * 16 + 4 * g + q4, dt, p4));
-                o[dt][0] = MFMA16(vf, pf0, o[dt][0]);
-                o[dt][1] = MFMA16(vf, pf1, o[dt][1]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[dt][qt] = MFMA16(vf, pf[qt], o[dt][qt]);
             }
         }
         if (valid) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const int q = qb * 32 + qt * 16 + li;
+            for (int qt = 0; qt < QT; ++qt) {
+                const int q = qb * QB + qt * 16 + li;
                 if (q < N) {
                     const float inv = 1.0f / sum[qt];
                     bf16* dst = (bf16*)a.o + ((long)img * N + q) * (H * 64) + h * 64 + 4 * g;
