@@ -23,6 +23,8 @@ gv_patchify_args = _struct("gv_patchify_args", [
     ("tiles", vp), ("patches", vp), ("n_img", i32), ("tile_h", i32), ("tile_w", i32), ("img_stride", i64),
     ("n_win", i32), ("win_y", i32 * 16), ("win_x", i32 * 16), ("crop", i32), ("mean", f32 * 3), ("std", f32 * 3),
     ("n_tiles", i32)])
+gv_crop_resize_args = _struct("gv_crop_resize_args", [
+    ("tiles", vp), ("out", vp), ("boxes", vp), ("n_crops", i32), ("n_tiles", i32), ("tile_h", i32), ("tile_w", i32), ("out_size", i32)])
 gv_layernorm_fwd_args = _struct("gv_layernorm_fwd_args", [
     ("x", vp), ("x_stride", i64), ("gamma", vp), ("beta", vp), ("y", vp), ("mean", vp), ("rstd", vp),
     ("rows", i32), ("D", i32), ("eps", f32)])
@@ -73,7 +75,7 @@ gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
 
 # entry point -> argument struct (every `int gv_*(const args*, void* stream)` of the header)
 ENTRY_POINTS = {
-    "gv_patchify": gv_patchify_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
+    "gv_patchify": gv_patchify_args, "gv_crop_resize": gv_crop_resize_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
     "gv_colsum_finalize": gv_colsum_finalize_args, "gv_ln_finalize": gv_ln_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
     "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_cls_rows": gv_cls_rows_args,
     "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,

@@ -67,7 +67,67 @@ __global__ __launch_bounds__(256) void patchify_kernel(gv_patchify_args a, int P
     }
 }
 
+// ---- random-resized-crop (+ horizontal flip) of NHWC u8 tiles: the DINO multi-crop input
+// stage.  Semantics = torchvision's tensor-mode resized_crop with
+// antialias off: the box (y0, x0, h, w) of the tile is resampled to out x out with
+// F.interpolate(float32, mode='bilinear', align_corners=False), rounded half-to-even and
+// clamped to u8; flip mirrors the OUTPUT columns.  One thread per 4 output pixels (12
+// contiguous bytes); float32 arithmetic in the oracle's association, no FMA contraction,
+// so the bytes are reproducible against the CPU restatement.
+__global__ __launch_bounds__(256) void crop_resize_kernel(gv_crop_resize_args a) {
+#pragma clang fp contract(off)
+    const int out = a.out_size, q = out >> 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.n_crops * out * q;
+    if (t >= total) return;
+    const int xq = (int)(t % q);
+    const int oy = (int)((t / q) % out);
+    const int n = (int)(t / ((long)q * out));
+    const int* bx = a.boxes + n * 6;
+    const int tile = bx[0], y0 = bx[1], x0 = bx[2], h = bx[3], w = bx[4], flip = bx[5];
+    const uint8_t* src = a.tiles + (long)tile * a.tile_h * a.tile_w * 3;
+    const float sy = (float)h / (float)out, sx = (float)w / (float)out;
+    float fy = sy * ((float)oy + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int iy0 = (int)fy, iy1 = iy0 + (iy0 < h - 1 ? 1 : 0);
+    const float ly = fy - (float)iy0, ly0 = 1.0f - ly;
+    const uint8_t* r0 = src + ((long)(y0 + iy0) * a.tile_w + x0) * 3;
+    const uint8_t* r1 = src + ((long)(y0 + iy1) * a.tile_w + x0) * 3;
+    uint32_t pk[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int oxo = xq * 4 + i;                       // output column
+        const int ox = flip ? out - 1 - oxo : oxo;        // column of the un-flipped resample
+        float fx = sx * ((float)ox + 0.5f) - 0.5f;
+        fx = fx < 0.f ? 0.f : fx;
+        const int ix0 = (int)fx, ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
+        const float lx = fx - (float)ix0, lx0 = 1.0f - lx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = lx0 * (float)r0[ix0 * 3 + c] + lx * (float)r0[ix1 * 3 + c];
+            const float bot = lx0 * (float)r1[ix0 * 3 + c] + lx * (float)r1[ix1 * 3 + c];
+            float v = __builtin_rintf(ly0 * top + ly * bot);
+            v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+            const int b = i * 3 + c;
+            pk[b >> 2] |= (uint32_t)v << (8 * (b & 3));
+        }
+    }
+    uint32_t* dst = (uint32_t*)(a.out + ((long)n * out * out + (long)oy * out + xq * 4) * 3);
+    dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2];
+}
+
 }  // namespace
+
+extern "C" int gv_crop_resize(const gv_crop_resize_args* a, void* stream) {
+    GV_REQUIRE(a && a->tiles && a->out && a->boxes, GV_E_NULL, "gv_crop_resize: null pointer");
+    GV_REQUIRE(a->n_crops > 0 && a->n_tiles > 0 && a->tile_h > 0 && a->tile_w > 0, GV_E_SHAPE, "gv_crop_resize: bad shape");
+    GV_REQUIRE(a->out_size > 0 && a->out_size % 4 == 0, GV_E_SHAPE, "gv_crop_resize: out_size=%d must be a positive multiple of 4", a->out_size);
+    GV_REQUIRE(gv_aligned(a->out, 4) && gv_aligned(a->boxes, 4), GV_E_ALIGN, "gv_crop_resize: out / boxes must be 4-byte aligned");
+    const long total = (long)a->n_crops * a->out_size * (a->out_size / 4);
+    hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_crop_resize");
+    return GV_OK;
+}
 
 extern "C" int gv_patchify(const gv_patchify_args* a, void* stream) {
     GV_REQUIRE(a && a->tiles && a->patches, GV_E_NULL, "gv_patchify: null pointer");

@@ -248,13 +248,15 @@ class VitRunner:
 
     # ---- forward: tiles -> CLS features written into feats[row_off + seg.img0 ...]
     def forward(self, W: Weights, G: VitGroup, tiles_u8, windows, mean, std, feats, row_off: int = 0):
-        """windows: one list of (y0, x0) crop origins per segment."""
+        """windows: one list of (y0, x0) crop origins per segment; tiles_u8: one NHWC u8 tensor for all
+        segments, or one per segment (pre-cut crops: each with the single window (0, 0))."""
         D, T, H = self.D, G.T, self.H
         E = L
         pos_full = W.f("pos_embed").view(-1, D)
         x0 = G.xbuf(0)
-        for sg, wins in zip(G.segs, windows):
-            ops.patchify(tiles_u8, wins, sg.crop, mean, std, out=sg.patches)
+        for k, (sg, wins) in enumerate(zip(G.segs, windows)):
+            src = tiles_u8[k] if isinstance(tiles_u8, (list, tuple)) else tiles_u8
+            ops.patchify(src, wins, sg.crop, mean, std, out=sg.patches)
             if sg.pos is None:
                 pos = pos_full
             else:   # interpolate_pos_encoding: row 0 = cls pos, rows 1.. = M @ pos[1:]
@@ -468,6 +470,8 @@ class DinoEngine:
         D = ARCHS[arch]["embed_dim"]
         self.D, self.K, self.G, self.V = D, out_dim, n_global, n_global + n_local
         self.mean, self.std = tuple(mean), tuple(std)
+        self.gsize, self.lsize = gsize, lsize
+        self._gcrops = self._lcrops = None       # crop buffers of the random-resized-crop path (allocated on first use)
         if windows is None:   # deterministic crop windows of SURVEY 8(d): (y0, x0)
             windows = [(16 * g, 16 * g) for g in range(n_global)] + [(20 * l, 160 - 20 * l) for l in range(n_local)]
         self.gwins, self.lwins = list(windows[:n_global]), list(windows[n_global:])
@@ -556,7 +560,7 @@ class DinoEngine:
         vals[L.HYP_STUDENT_TEMP] = self.ts
         ops.store_f32(self.hyper, vals)
 
-    def forward_backward(self, tiles_u8: torch.Tensor, micro: Tuple[int, int] = (0, 1)):
+    def forward_backward(self, tiles_u8: torch.Tensor, micro: Tuple[int, int] = (0, 1), boxes=None):
         """teacher fwd (global crops) -> student fwd (all crops) -> loss -> backward.
         Leaves gradients in arena.g, loss in self.loss, center_sum.  ``micro = (j, n)``: this is
         micro-batch j of n (gradient accumulation): gradients, loss and centre sums add up over
@@ -567,6 +571,21 @@ class DinoEngine:
         first, last = mj == 0, mj == mn - 1
         if first:
             a.g.zero_()
+        t_src, t_win, s_src, s_win = tiles_u8, [self.gwins], tiles_u8, self.s_wins
+        if boxes is not None:
+            # random-resized crops (multicrop.MultiCropSampler): cut on the device, then every crop is its own
+            # "tile" with the single window (0, 0); rows stay crop-major like the fixed windows
+            bg, bl = boxes
+            assert bg.shape[0] == self.G * B and (self.V == self.G or bl.shape[0] == (self.V - self.G) * B)
+            if self._gcrops is None:
+                self._gcrops = _empty((self.G * B, self.gsize, self.gsize, 3), torch.uint8, self.dev)
+                self._lcrops = _empty(((self.V - self.G) * B, self.lsize, self.lsize, 3), torch.uint8, self.dev) if self.V > self.G else None
+            ops.crop_resize(tiles_u8, bg, self.gsize, out=self._gcrops)
+            t_src, t_win = self._gcrops, [[(0, 0)]]
+            s_src, s_win = [self._gcrops], [[(0, 0)]]
+            if self.V > self.G:
+                ops.crop_resize(tiles_u8, bl, self.lsize, out=self._lcrops)
+                s_src.append(self._lcrops); s_win.append([(0, 0)])
         # the teacher's forward shares nothing with the student's until the loss: it runs on the
         # side stream beside the student forward (fills the tail of each other's kernels)
         side = self.vit.side if (tiles_u8.is_cuda and not torch.cuda.is_current_stream_capturing()) else None
@@ -574,13 +593,13 @@ class DinoEngine:
             main = torch.cuda.current_stream()
             self._ev_fork.record(main); side.wait_event(self._ev_fork)
             with torch.cuda.stream(side):
-                self.vit.forward(self.tW, self.g_teach, tiles_u8, [self.gwins], self.mean, self.std, self.hb_t.feats)
+                self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats)
                 self.head.forward(self.tH, self.wn_t, self.hb_t)
                 self._ev_join.record(side)
         else:
-            self.vit.forward(self.tW, self.g_teach, tiles_u8, [self.gwins], self.mean, self.std, self.hb_t.feats)
+            self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats)
             self.head.forward(self.tH, self.wn_t, self.hb_t)
-        self.vit.forward(self.sW, self.g_stu, tiles_u8, self.s_wins, self.mean, self.std, self.hb_s.feats)
+        self.vit.forward(self.sW, self.g_stu, s_src, s_win, self.mean, self.std, self.hb_s.feats)
         self.head.forward(self.sH, self.wn_s, self.hb_s)
         if side is not None:
             main.wait_event(self._ev_join)
@@ -652,12 +671,13 @@ class DinoEngine:
             self._n_micro = 1
         return self.loss
 
-    def step(self, tiles_u8: torch.Tensor, **sched) -> torch.Tensor:
+    def step(self, tiles_u8: torch.Tensor, boxes=None, **sched) -> torch.Tensor:
         """One full training step on [B, tile, tile, 3] uint8 NHWC tiles.  Returns the
-        (device, un-synchronised) loss tensor."""
+        (device, un-synchronised) loss tensor.  ``boxes``: (global, local) int32 device tensors from
+        multicrop.MultiCropSampler.sample -- random-resized crops instead of the fixed parity windows."""
         assert tiles_u8.shape == (self.B, self.tile, self.tile, 3) and tiles_u8.dtype == torch.uint8
         self.set_hyper(**sched)
-        self.forward_backward(tiles_u8)
+        self.forward_backward(tiles_u8, boxes=boxes)
         self.optimizer_step()
         return self.loss
 

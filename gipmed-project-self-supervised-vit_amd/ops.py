@@ -47,6 +47,21 @@ def patchify(tiles_u8: torch.Tensor, windows: Sequence[Sequence[int]], crop: int
     return out
 
 
+def crop_resize(tiles_u8: torch.Tensor, boxes: torch.Tensor, out_size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Random-resized crops on the device: tiles_u8 [n_tiles, H, W, 3] u8, boxes int32 [n, 6] =
+    (tile, y0, x0, h, w, flip) on the same device -> u8 [n, out_size, out_size, 3]; see gv_crop_resize."""
+    _chk(tiles_u8, torch.uint8, "tiles")
+    assert tiles_u8.dim() == 4 and tiles_u8.shape[-1] == 3 and tiles_u8.is_contiguous()
+    assert boxes.dtype == torch.int32 and boxes.dim() == 2 and boxes.shape[1] == 6 and boxes.is_contiguous() and boxes.device == tiles_u8.device
+    n = boxes.shape[0]
+    if out is None:
+        out = torch.empty(n, out_size, out_size, 3, dtype=torch.uint8, device=tiles_u8.device)
+    a = L.gv_crop_resize_args(tiles_u8.data_ptr(), out.data_ptr(), boxes.data_ptr(), n, tiles_u8.shape[0], tiles_u8.shape[1],
+                              tiles_u8.shape[2], out_size)
+    L.call("gv_crop_resize", a, _stream())
+    return out
+
+
 def layernorm_fwd(x, gamma, beta, rows: int, D: int, x_stride: Optional[int] = None, eps: float = 1e-6,
                   y=None, mean=None, rstd=None):
     _chk(x, f32, "x")

@@ -12,7 +12,8 @@ string is used AS the transform: that is the user's augmentation hook.  Of the n
 recipes only the geometric, byte-exact ones run here (flips, 90-degree rotations, the
 'none' recipe); the PIL colour / blur / affine / cutout recipes are CPU augmentation outside
 this build's scope and raise NotImplementedError instead of silently
-doing something else.
+doing something else.  The DINO random-resized crops + flips are cut on the device instead
+(gipvit.multicrop.MultiCropSampler + gv_crop_resize).
 """
 from __future__ import annotations
 

@@ -66,6 +66,21 @@ typedef struct {
 } gv_patchify_args;
 int gv_patchify(const gv_patchify_args* a, void* stream);
 
+/* ---- random-resized crops of the tiles (DINO multi-crop input stage; absent from the
+ * reference, whose tiles are augmented on the CPU by transformations.py:103-209 -- SURVEY 8f rank 1).
+ * For crop n: box (y0, x0, h, w) of tile `tile` is resampled to out_size x out_size with
+ * torchvision's tensor-mode semantics (float32 bilinear, align_corners=False, no antialias,
+ * round half to even, clamp) and mirrored left-right when flip != 0.
+ * boxes: device int32 [n_crops][6] = {tile, y0, x0, h, w, flip}; the box must lie inside the
+ * tile (the caller checks: the values are device-resident).  out: u8 [n_crops, out, out, 3].   */
+typedef struct {
+    const uint8_t* tiles;  /* [n_tiles, tile_h, tile_w, 3] u8 (NHWC) */
+    uint8_t* out;
+    const int32_t* boxes;
+    int32_t n_crops, n_tiles, tile_h, tile_w, out_size;
+} gv_crop_resize_args;
+int gv_crop_resize(const gv_crop_resize_args* a, void* stream);
+
 /* ---- LayerNorm (nn.LayerNorm(D, eps=1e-6); vit.pyc@L138,142,195) -------
  * fwd: x f32 rows -> y bf16 rows (+ mean, rstd f32 per row).
  * D must be 192, 384 or 768.  Row r of x lives at x + r*x_stride.        */

@@ -153,6 +153,36 @@ def test_dino_micro_batches_equal_full_batch(dev):
         assert _rel(sm[k], sf[k]) < 1e-3, k
 
 
+@gpu
+def test_dino_random_crops(dev):
+    """Random-resized-crop path: boxes that equal the fixed parity windows (scale 1, no flip) reproduce the
+    window path (same loss, same update up to summation order); sampled boxes give a finite loss and the crops the oracle's restatement cuts."""
+    import numpy as np
+    from gipvit.engine import DinoEngine
+    from gipvit.multicrop import MultiCropSampler
+    from oracle import vit_oracle as vo, augment_oracle as ao
+    K, B = 1024, 2
+    p, hp = vo.init_vit("vit_tiny", 224, 0, seed=0), vo.init_dino_head(192, K, seed=1)
+    tiles = vo.synth_tiles(B, 256, seed=5).to(dev)
+    a = DinoEngine(arch="vit_tiny", img_size=224, out_dim=K, batch=B, lr=1e-4, device=dev)
+    b = DinoEngine(arch="vit_tiny", img_size=224, out_dim=K, batch=B, lr=1e-4, device=dev)
+    a.load_state(p, hp); b.load_state(p, hp)
+    bg = torch.tensor([[i, y, x, 224, 224, 0] for (y, x) in a.gwins for i in range(B)], dtype=torch.int32, device=dev)
+    bl = torch.tensor([[i, y, x, 96, 96, 0] for (y, x) in a.lwins for i in range(B)], dtype=torch.int32, device=dev)
+    la, lb = float(a.step(tiles)), float(b.step(tiles, boxes=(bg, bl)))
+    torch.cuda.synchronize()
+    assert la == lb, (la, lb)                       # identical crops -> identical forward
+    for k, v in a.backbone_state_dict().items():    # backward sums use atomics: equal up to summation order
+        assert _rel(b.backbone_state_dict()[k], v) < 1e-3, k
+    sm = MultiCropSampler(batch=B, tile=256, seed=11)
+    g, l = sm.sample(dev)
+    loss = float(b.step(tiles, boxes=(g, l)))
+    torch.cuda.synchronize()
+    assert np.isfinite(loss) and 0.0 < loss < 20.0
+    ref = ao.crop_resize(tiles.cpu().numpy(), l.cpu().numpy(), 96)
+    assert np.array_equal(b._lcrops.cpu().numpy(), ref)
+
+
 @pytest.mark.graph_experimental
 def test_dino_graph_replay_matches_eager(dev):
     """The captured hipGraph step and the eager step follow the same loss trajectory.

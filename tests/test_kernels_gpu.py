@@ -129,6 +129,29 @@ def test_linear_rejects_bad_shapes(dev):
         ops().linear(A, B, C, 64, 64, 100, lda=104, ldb=104)
 
 
+def test_linear_timing_rows(dev):
+    """gv_linear_timing: HIP-event timing of the GEMM launches, one row per kernel instantiation."""
+    o = ops()
+    A, B = ints((256, 384), dev, seed=1), ints((128, 384), dev, seed=2)
+    C = torch.empty(256, 128, dtype=bf16, device=dev)
+    Ct, Bt = torch.zeros(384, 128, dtype=f32, device=dev), ints((256, 128), dev, seed=3)
+    o.linear(A, B, C, 256, 128, 384)                                   # outside the window: not recorded
+    o.linear_timing(True)
+    for _ in range(3):
+        o.linear(A, B, C, 256, 128, 384)                               # NT, bf16 out, epilogue 0
+    o.linear(A, Bt, Ct, 384, 128, 256, trans_a=True, trans_b=True)     # TN, f32 out, epilogue 0
+    o.linear_timing(False)
+    o.linear(A, B, C, 256, 128, 384)
+    rows = {r["kernel"]: r for r in o.linear_timing_read()}
+    nt = rows["gemm_kernel<false, false, bf16, false, 0>"]
+    tn = rows["gemm_kernel<true, true, float, false, 0>"]
+    assert len(rows) == 2 and nt["launches"] == 3 and tn["launches"] == 1
+    assert nt["flops"] == 3 * 2.0 * 256 * 128 * 384 and tn["flops"] == 2.0 * 384 * 128 * 256
+    assert 0.0 < nt["seconds"] < 1.0 and 0.0 < tn["seconds"] < 1.0
+    o.linear_timing(True); o.linear_timing(False)                      # a new window starts empty
+    assert o.linear_timing_read() == []
+
+
 # ------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("D", [192, 384, 768])
 def test_layernorm_fwd_bwd(dev, D):
@@ -386,3 +409,24 @@ def test_adamw_ema(dev):
             o.adamw_ema(p3, grad * step, m, v, None, None, None, n, lr=1e-3 if mode == 1 else 1e-2, beta1=0.9, beta2=0.999, eps=1e-8,
                         weight_decay=0.01, step=step, mode=mode)
         close(p3, pr.detach(), 1e-5, 1e-6, f"optimizer mode {mode}")
+
+
+def test_crop_resize(dev):
+    """gv_crop_resize vs the CPU restatement: same float32 arithmetic in the same association -> identical bytes."""
+    import numpy as np
+    from oracle import augment_oracle as ao
+    rng = np.random.default_rng(0)
+    tiles = rng.integers(0, 256, (4, 256, 256, 3), dtype=np.uint8)
+    boxes = []
+    for n in range(24):
+        y0, x0, h, w = ao.sample_box(rng, 256, 256, (0.05, 1.0))
+        boxes.append((n % 4, y0, x0, h, w, n % 2))
+    boxes += [(1, 16, 16, 224, 224, 0), (2, 0, 0, 256, 256, 1), (3, 100, 50, 1, 1, 0), (0, 255, 0, 1, 256, 1)]
+    boxes = np.array(boxes, np.int32)
+    t_dev, b_dev = torch.from_numpy(tiles).to(dev), torch.from_numpy(boxes).to(dev)
+    for out in (96, 224):
+        got = ops().crop_resize(t_dev, b_dev, out).cpu().numpy()
+        ref = ao.crop_resize(tiles, boxes, out)
+        assert np.array_equal(got, ref), (out, int((got != ref).sum()), int(np.abs(got.astype(int) - ref.astype(int)).max()))
+    with pytest.raises(L().GipvitError, match="multiple of 4"):
+        ops().crop_resize(t_dev, b_dev, 98)

@@ -151,3 +151,43 @@ def test_golden_dino_tiny():
     assert abs(float(loss) - float(gold["loss"])) < 1e-4
     assert np.allclose(s_out.numpy()[:, :64], gold["student"], atol=1e-4)
     assert np.allclose(grads["head.last_layer.weight_v"].numpy()[:4, :32], gold["g_last"], atol=1e-6, rtol=1e-3)
+
+
+def test_crop_resize_oracle_vs_torch_interpolate():
+    """oracle/augment_oracle.crop_resize restates torchvision's tensor-mode resized_crop (float32 bilinear,
+    align_corners=False, no antialias, round, clamp); torch.nn.functional.interpolate pins it.  The two may
+    differ by one count where the float result sits on a rounding boundary (association / FMA), nowhere else."""
+    import torch.nn.functional as F
+    from oracle import augment_oracle as ao
+    rng = np.random.default_rng(0)
+    tiles = rng.integers(0, 256, (3, 64, 64, 3), dtype=np.uint8)
+    boxes = np.array([[0, 0, 0, 64, 64, 0], [1, 5, 9, 40, 31, 0], [2, 10, 3, 17, 50, 1], [0, 20, 20, 8, 8, 1], [1, 0, 0, 64, 64, 1]], np.int32)
+    for out in (32, 96):
+        got = ao.crop_resize(tiles, boxes, out)
+        for n, (t, y0, x0, h, w, flip) in enumerate(boxes.tolist()):
+            src = torch.from_numpy(tiles[t, y0:y0 + h, x0:x0 + w].copy()).permute(2, 0, 1)[None].float()
+            ref = F.interpolate(src, size=(out, out), mode="bilinear", align_corners=False).round().clamp(0, 255)[0].permute(1, 2, 0).numpy()
+            ref = ref[:, ::-1] if flip else ref
+            d = np.abs(got[n].astype(np.int32) - ref.astype(np.int32))
+            assert d.max() <= 1 and (d != 0).mean() < 5e-3, (out, n, d.max(), (d != 0).mean())   # ties only (torch contracts to FMA)
+    # a box of the output's own size is a copy (and a mirrored copy)
+    same = ao.crop_resize(tiles, np.array([[2, 7, 11, 32, 32, 0], [2, 7, 11, 32, 32, 1]], np.int32), 32)
+    assert np.array_equal(same[0], tiles[2, 7:39, 11:43]) and np.array_equal(same[1], tiles[2, 7:39, 11:43][:, ::-1])
+
+
+def test_multicrop_sampler_boxes():
+    """Host sampler: boxes stay inside the tile, areas follow the scale ranges, rows are crop-major."""
+    from gipvit.multicrop import MultiCropSampler
+    sm = MultiCropSampler(batch=16, tile=256, seed=3)
+    g, l = sm.sample()
+    assert g.shape == (32, 6) and l.shape == (128, 6) and g.dtype == torch.int32
+    for b, lo, hi in ((g, 0.4, 1.0), (l, 0.05, 0.4)):
+        b = b.numpy()
+        assert (b[:, 0] == np.tile(np.arange(16), len(b) // 16)).all()
+        assert (b[:, 1] >= 0).all() and (b[:, 2] >= 0).all() and (b[:, 1] + b[:, 3] <= 256).all() and (b[:, 2] + b[:, 4] <= 256).all()
+        frac = b[:, 3] * b[:, 4] / 65536.0
+        assert frac.min() >= lo * 0.97 and frac.max() <= hi * 1.03
+        assert 0.2 < b[:, 5].mean() < 0.8
+    from oracle import augment_oracle as ao        # same algorithm, restated
+    y0, x0, h, w = ao.sample_box(np.random.default_rng(1), 256, 256, (0.05, 0.4))
+    assert 0 <= y0 and y0 + h <= 256 and 0 <= x0 and x0 + w <= 256

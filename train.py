@@ -64,6 +64,10 @@ def build_parser():
     g.add_argument("--local-crops-number", type=int, default=8)
     g.add_argument("--global-crop-size", type=int, default=224)
     g.add_argument("--local-crop-size", type=int, default=96)
+    g.add_argument("--random-crops", action="store_true", help="DINO: random-resized crops + flips cut on the device every step "
+                   "(gv_crop_resize); default = the fixed parity windows")
+    g.add_argument("--global-crops-scale", type=float, nargs=2, default=(0.4, 1.0))
+    g.add_argument("--local-crops-scale", type=float, nargs=2, default=(0.05, 0.4))
     g.add_argument("--momentum-teacher", type=float, default=0.996)
     g.add_argument("--teacher-temp", type=float, default=0.04)
     g.add_argument("--warmup-teacher-temp", type=float, default=0.04)
@@ -199,6 +203,11 @@ def main(argv=None):
     total_updates = args.epochs * updates_per_epoch
     use_graph = args.dino and args.graph
     feats_out = []
+    sampler = None
+    if args.dino and args.random_crops:       # DINO recipe: random-resized crops + flips, cut on the device
+        from gipvit.multicrop import MultiCropSampler
+        sampler = MultiCropSampler(B, tile, 2, args.local_crops_number, tuple(args.global_crops_scale), tuple(args.local_crops_scale),
+                                   seed=args.seed + rank)
 
     # ---- epoch loop (train.py:905-977) / step loop (988-1143)
     for epoch in range(start_epoch, args.epochs):
@@ -230,7 +239,7 @@ def main(argv=None):
                         eng.capture(data)
                     loss_t = eng.step_graph(data, **sch)
                 else:
-                    loss_t = eng.step(data, **sch)
+                    loss_t = eng.step(data, boxes=sampler.sample(dev) if sampler is not None else None, **sch)
             else:
                 loss_t = eng.step(data, target, lr=cur_lr)
                 probs.append(eng.prob[:, 1].clone() if eng.C > 1 else eng.prob[:, 0].clone()); targets.append(target.view(-1))
