@@ -171,7 +171,7 @@ def test_dino_random_crops(dev):
     bl = torch.tensor([[i, y, x, 96, 96, 0] for (y, x) in a.lwins for i in range(B)], dtype=torch.int32, device=dev)
     la, lb = float(a.step(tiles)), float(b.step(tiles, boxes=(bg, bl)))
     torch.cuda.synchronize()
-    assert la == lb, (la, lb)                       # identical crops -> identical forward
+    assert abs(la - lb) <= 1e-5, (la, lb)           # identical crops -> identical forward (the loss sum itself uses atomics)
     for k, v in a.backbone_state_dict().items():    # backward sums use atomics: equal up to summation order
         assert _rel(b.backbone_state_dict()[k], v) < 1e-3, k
     sm = MultiCropSampler(batch=B, tile=256, seed=11)
