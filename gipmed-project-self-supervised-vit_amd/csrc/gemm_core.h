@@ -275,7 +275,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         const int lcol = (LPR >= 64 ? lane : lane % LPR) * W;
         const int epi = EPI >= 0 ? EPI : g.epi;
         const int N = g.N, M = g.M;
-        constexpr bool PREFETCH = !ATOMIC && EPI >= 0 && (EPI & (GV_EPI_RESID | GV_EPI_POS | GV_EPI_ACCUM | GV_EPI_DGELU)) != 0;
+        constexpr bool PREFETCH = !ATOMIC && EPI >= 0 && (EPI & (GV_EPI_RESID | GV_EPI_POS | GV_EPI_ACCUM | GV_EPI_DGELU)) != 0 && FM <= 4 && C::SCHED != 10;
         constexpr bool BIAS_EARLY = !ATOMIC && EPI >= 0 && (EPI & GV_EPI_BIAS) != 0 && CPI == 1;
         f32x4 pre_b[W / 4 > 0 ? W / 4 : 1];
         if constexpr (BIAS_EARLY) {
@@ -328,6 +328,48 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         GV_STAMP(t_loop0);
 #endif
         int c_stage = 0;
+        if constexpr (C::SCHED == 10) {
+            // ---- PING-PONG k-loop (lab): the workgroup's two halves of wave rows (SIMD partners: waves w and w + NW/2)
+            // alternate roles every half step: while one group issues the LDS-DMA of step t + PD and reads its
+            // fragments of step t, the other runs the MFMAs of the step it read before.  Two barriers per step;
+            // before the second one every wave has waited for its pieces of step t + 1 (counted vmcnt) and for
+            // its fragment reads (lgkmcnt(0)), so the next reader finds the stage landed and the next LDS-DMA
+            // finds its target stage (last read one step ago) free.
+            static_assert(C::WM % 2 == 0 && C::KS == 1 && PD >= 2, "ping-pong: an even number of wave rows, BK = 32");
+            const int grp = wm / (C::WM / 2);
+            bf16x8 pa[FM], pb[FN];
+            auto reads = [&](int stage) {
+                GV_LDS char* cur = smem + stage * C::STAGE;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) pb[j] = read_frag<TB, BN, BK>(cur + C::A_BYTES, wn * FN + j, 0, lane);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) pa[i] = read_frag<TA, BM, BK>(cur, wm * FM + i, 0, lane);
+            };
+            auto mfmas = [&]() {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb[j], pa[i], acc[i][j], 0, 0, 0);
+            };
+            auto wait_young = [&](int young) {
+                if (young >= 2) wait_vmcnt<C::GLDS * 2>();
+                else if (young == 1) wait_vmcnt<C::GLDS>();
+                else wait_vmcnt<0>();
+            };
+            wait_young(min(PD, it.nt) - 1);                  // step 0 landed (mine)
+            __builtin_amdgcn_s_barrier();
+            for (int t = 0; t < it.nt; ++t) {
+                if (grp == 0) { issue(); reads(c_stage); __builtin_amdgcn_s_waitcnt(0xC07F); }
+                else if (t > 0) mfmas();
+                __builtin_amdgcn_s_barrier();
+                if (grp == 0) mfmas();
+                else { issue(); reads(c_stage); __builtin_amdgcn_s_waitcnt(0xC07F); }
+                wait_young(max(0, min(PD - 1, it.nt - 2 - t)));   // step t + 1 landed (mine); t + 2.. may fly
+                __builtin_amdgcn_s_barrier();
+                c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+            }
+            if (grp == 1) mfmas();
+        } else
         for (int t = 0; t < it.nt; ++t) {
             GV_STAMP(ts0);
             // this step's pieces (mine) landed: everything but the younger in-flight steps

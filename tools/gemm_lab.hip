@@ -53,10 +53,14 @@ float run_cfg(const Shape& sh, GemmP p, int reps, int persistent_mult, int order
 
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
 
+static std::vector<std::vector<unsigned char>> g_ref;     // first configuration's output per shape (byte compare)
+
 template <class C>
 void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void* B, void* Cb, void* ref, float* bias, void* aux,
              float* resid) {
+    int shape_idx = -1;
     for (const auto& sh : shapes) {
+        ++shape_idx;
         GemmP p{};
         p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = Cb; p.M = sh.M; p.N = sh.N; p.K = sh.K;
         p.lda = sh.ta ? sh.M : sh.K; p.ldb = sh.tb ? sh.N : sh.K; p.ldc = sh.N;
@@ -80,6 +84,25 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
                     t = run_cfg<C, true, true, float, 0>(sh, p, 10, pm, order);
                 }
                 best[v] = std::min(best[v], t);
+            }
+        }
+        {   // correctness against the first configuration run on this shape: one more full launch, then compare bytes
+            p.epi = sh.epi;
+            const size_t bytes = (size_t)sh.M * sh.N * (sh.cf32 ? 4 : 2);
+            CK(hipMemset(Cb, 0xFF, bytes));
+            if (!sh.ta && !sh.tb) {
+                if (sh.epi == GV_EPI_BIAS) run_cfg<C, false, false, bf16, GV_EPI_BIAS>(sh, p, 1, 0, 0);
+                else if (sh.epi == (GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE)) run_cfg<C, false, false, bf16, GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE>(sh, p, 1, 0, 0);
+                else run_cfg<C, false, false, float, GV_EPI_BIAS | GV_EPI_RESID>(sh, p, 1, 0, 0);
+            } else if (!sh.ta && sh.tb) run_cfg<C, false, true, bf16, 0>(sh, p, 1, 0, 0);
+            else run_cfg<C, true, true, float, 0>(sh, p, 1, 0, 0);
+            std::vector<unsigned char> h(bytes);
+            CK(hipMemcpy(h.data(), Cb, bytes, hipMemcpyDeviceToHost));
+            if ((int)g_ref.size() <= shape_idx) { g_ref.resize(shape_idx + 1); g_ref[shape_idx] = h; }
+            else {
+                size_t bad = 0;
+                for (size_t i = 0; i < bytes; ++i) bad += h[i] != g_ref[shape_idx][i];
+                if (bad) printf("   !! %s %s: %zu of %zu output bytes differ from the first configuration\n", cname, sh.name, bad, bytes);
             }
         }
         const double fl = 2.0 * sh.M * sh.N * sh.K;
@@ -116,8 +139,9 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(A, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), nB * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, 4096 * 4)); CK(hipMemset(resid, 0, nC * 4)); CK(hipMemset(aux, 0, nC * 2));
     //            BM   BN  BK WM WN NSTAGE SCHED
-    if (only_cfg < 0 || only_cfg == 0) run_all<Cfg<128, 128, 64, 2, 2, 2, 0>>("128x128", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 1) run_all<Cfg<96, 128, 64, 2, 2, 2, 0>>("96x128", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 2) run_all<Cfg<64, 128, 64, 2, 2, 2, 0>>("64x128", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 0) run_all<Cfg<128, 128, 64, 2, 2, 2, 0>>("128x128 k64 (production)", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 1) run_all<Cfg<256, 256, 32, 2, 4, 4, 10>>("256x256 k32 pingpong", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 2) run_all<Cfg<256, 256, 32, 4, 4, 4, 10>>("256x256 k32 pingpong 16w", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (only_cfg < 0 || only_cfg == 3) run_all<Cfg<256, 128, 32, 2, 4, 4, 10>>("256x128 k32 pingpong", shapes, A, B, C, nullptr, bias, aux, resid);
     return 0;
 }
