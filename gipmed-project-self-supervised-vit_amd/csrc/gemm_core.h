@@ -358,17 +358,28 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             };
             wait_young(min(PD, it.nt) - 1);                  // step 0 landed (mine)
             __builtin_amdgcn_s_barrier();
+            // one code path for both halves; the second half runs it one barrier late (and the first half
+            // takes one extra barrier at the end), so its memory phase lines up with the other's MFMA phase
+            if (grp == 1) __builtin_amdgcn_s_barrier();
             for (int t = 0; t < it.nt; ++t) {
-                if (grp == 0) { issue(); reads(c_stage); __builtin_amdgcn_s_waitcnt(0xC07F); }
-                else if (t > 0) mfmas();
+                issue();
+                reads(c_stage);
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // fragments in registers before the barrier
+                wait_young(max(0, min(PD - 1, it.nt - 2 - t)));   // my pieces of step t + 1 landed; t + 2.. may fly
+                // sched_barrier: hipcc moves register-only MFMAs across s_barrier / s_waitcnt otherwise, which
+                // would put both halves' MFMAs into the same phase
+                __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
-                if (grp == 0) mfmas();
-                else { issue(); reads(c_stage); __builtin_amdgcn_s_waitcnt(0xC07F); }
-                wait_young(max(0, min(PD - 1, it.nt - 2 - t)));   // step t + 1 landed (mine); t + 2.. may fly
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                mfmas();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
                 c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
             }
-            if (grp == 1) mfmas();
+            if (grp == 0) __builtin_amdgcn_s_barrier();
         } else
         for (int t = 0; t < it.nt; ++t) {
             GV_STAMP(ts0);

@@ -125,6 +125,8 @@ int main(int argc, char** argv) {
         {"dX qkv(NN)", T, 384, 1152, false, true, 0, false},
         {"dX proj(NN)", T, 384, 384, false, true, 0, false},
         {"dX fc2(NN)", T, 1536, 384, false, true, 0, false},
+        {"square NT 4096^2 k2048", 4096, 4096, 2048, false, false, GV_EPI_BIAS, false},
+        {"square TN 4096^2 k2048", 4096, 4096, 2048, true, true, 0, true},
     };
     std::vector<Shape> shapes;
     for (int i = 0; i < (int)all_shapes.size(); ++i) if (only_shape < 0 || only_shape == i) shapes.push_back(all_shapes[i]);
