@@ -71,6 +71,7 @@ struct TileSrc {
     const bf16* ptr[PPW];
     bool ok[PPW];
     int r[PPW];
+    bool all_ok;          // wave-uniform: every lane's column chunk of every piece lies inside the operand
 
     __device__ __forceinline__ void setup(const bf16* __restrict__ base, long ld, int o0, int lim, int wave, int lane) {
         if constexpr (!T) {
@@ -84,6 +85,7 @@ struct TileSrc {
                 ptr[p] = base + (long)row * ld + c * 8;
                 ok[p] = true; r[p] = 0;
             }
+            all_ok = true;
         } else {
             constexpr int RB = R * 2, RPP = 1024 / RB, LPR = RB / 16;
 #pragma unroll
@@ -96,6 +98,10 @@ struct TileSrc {
                 r[p] = rr;
                 ptr[p] = ok[p] ? base + (long)rr * ld + col : (const bf16*)zero_page + (s16 & 15) * 8;
             }
+            bool every = true;
+#pragma unroll
+            for (int p = 0; p < PPW; ++p) every = every && ok[p];
+            all_ok = __builtin_amdgcn_ballot_w64(!every) == 0ull;
         }
     }
     // issue piece p of this wave's share of the k-step starting at reduction index k0
@@ -106,6 +112,17 @@ struct TileSrc {
         glds16(src, tile + (wave * PPW + p) * 1024);
     }
     __device__ __forceinline__ void issue(long ld, int k0, int klim, GV_LDS char* tile, int wave) const {
+        if constexpr (T) {
+            // whole step inside the reduction range and every column of this wave's pieces valid (the hot
+            // shapes, always): no per-lane predicate -- the compare / select per piece are VALU work that
+            // competes with the partner wave's MFMA issue
+            if (all_ok && k0 + BK <= klim) {
+                const long off = (long)k0 * ld;
+#pragma unroll
+                for (int p = 0; p < PPW; ++p) glds16(ptr[p] + off, tile + (wave * PPW + p) * 1024);
+                return;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < PPW; ++p) issue_one(p, ld, k0, klim, tile, wave);
     }
