@@ -243,7 +243,10 @@ class VitRunner:
         self.one = torch.ones(1, dtype=f32, device=device)
         self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
         cuda = torch.device(device).type == "cuda"
-        self.side = torch.cuda.Stream(device) if cuda and os.environ.get("GIPVIT_DW_STREAM", "1") != "0" else None
+        self.side = None
+        if cuda and os.environ.get("GIPVIT_DW_STREAM", "1") != "0":
+            prio = os.environ.get("GIPVIT_SIDE_PRIORITY")
+            self.side = torch.cuda.Stream(device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device)
         self._events: List[torch.cuda.Event] = []
 
     # ---- forward: tiles -> CLS features written into feats[row_off + seg.img0 ...]

@@ -209,6 +209,10 @@ def main(argv=None):
         sampler = MultiCropSampler(B, tile, 2, args.local_crops_number, tuple(args.global_crops_scale), tuple(args.local_crops_scale),
                                    seed=args.seed + rank)
 
+    # the step's critical path runs on a high-priority stream; the engine's side stream (teacher forward,
+    # weight-gradient GEMMs) fills the CU slots it leaves
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.Stream(dev, priority=-1))
     # ---- epoch loop (train.py:905-977) / step loop (988-1143)
     for epoch in range(start_epoch, args.epochs):
         batch_time, data_time, losses = Meter(), Meter(), Meter()
