@@ -239,6 +239,7 @@ class VitRunner:
         self.arch, self.D, self.depth, self.H, self.img_size = arch, a["embed_dim"], a["depth"], a["num_heads"], img_size
         self.scale = 64 ** -0.5
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
+        self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
         self.one = torch.ones(1, dtype=f32, device=device)
         self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
@@ -340,6 +341,25 @@ class VitRunner:
             if ev is not None:
                 main.wait_event(ev)
 
+        # LayerNorm backward leaves per-block column sums in a partials buffer; folding them into the gamma / beta /
+        # bias gradients (ln_finalize) is parameter-gradient work too, so it also goes to the side stream.  Three
+        # partials buffers rotate; one is rewritten only after the finalize that read it (three calls ago) has run.
+        ring, fin_ev, ring_i, last_side = self.partials_ring, [None, None, None], [0], [None]
+
+        def ln_bwd(dy, x, mean, rstd, gamma, gb, d0, d1, d2):
+            k = ring_i[0]
+            ring_i[0] = (k + 1) % 3
+            join(fin_ev[k])
+            ops.layernorm_bwd(dy, x, mean, rstd, gamma, G.g, gb, ring[k], T, D)
+            if side is None:
+                ops.ln_finalize(ring[k], L.LN_PARTIAL_BLOCKS, D, d0, d1, d2)
+                return
+            e0 = new_event(); e0.record(main); side.wait_event(e0)
+            with torch.cuda.stream(side):
+                ops.ln_finalize(ring[k], L.LN_PARTIAL_BLOCKS, D, d0, d1, d2)
+                e1 = new_event(); e1.record(side)
+            fin_ev[k] = last_side[0] = e1
+
         gbs = (G.gb, G.gb2)              # gb: dY of the MLP half, gb2: dY of the attention half
         done_fc1 = done_qkv = done_fc2 = done_proj = None
         for i in reversed(range(self.depth)):
@@ -351,8 +371,8 @@ class VitRunner:
             ops.linear(G.dh, W.w(b + "mlp.fc1.weight"), G.dxn, T, D, 4 * D, trans_b=True)
             done_fc1 = dw(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, colsum_a=W.g(b + "mlp.fc1.bias"))
             join(done_proj)              # last block's dW_proj read gb2
-            ops.layernorm_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), G.g, gbs[1], self.partials, T, D)
-            self._fin3(W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"))
+            ln_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), gbs[1],
+                   W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"))
             # attention
             ops.linear(gbs[1], W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             done_proj = dw(gbs[1], G.o[i], W.g(b + "attn.proj.weight"), D, D)
@@ -362,8 +382,8 @@ class VitRunner:
             ops.linear(G.dqkv, W.w(b + "attn.qkv.weight"), G.dxn, T, D, 3 * D, trans_b=True)
             done_qkv = dw(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, colsum_a=W.g(b + "attn.qkv.bias"))
             join(done_fc2)               # this block's dW_fc2 read gb
-            ops.layernorm_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), G.g, gbs[0], self.partials, T, D)
-            self._fin3(W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
+            ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gbs[0],
+                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
             if on_block_done is not None:
                 # the block's weight gradients are produced by the side stream: report the block from
                 # there, so a data-parallel all-reduce queues behind the dW products and main never waits
@@ -373,6 +393,7 @@ class VitRunner:
                     with torch.cuda.stream(side):
                         on_block_done(i)
         join(done_qkv)          # every dW product is in (the side stream runs them in order); ws is free again
+        join(last_side[0])      # ... and the last finalize
         # token assembly + patch embedding, per segment
         gpos = W.g("pos_embed").view(-1, D)
         for sg in G.segs:
