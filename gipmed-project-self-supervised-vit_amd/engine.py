@@ -436,6 +436,7 @@ class HeadRunner:
         self.D, self.K, self.hidden, self.bott = D, K, hidden, bott
         self.cs_ws = _empty((64 * max(hidden, bott),), f32, device)
         self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
+        self.ws_side = None                                                           # second one, for products queued on a side stream
 
     def forward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers):
         R, D, Hd, Bt, K, E = hb.R, self.D, self.hidden, self.bott, self.K, L
@@ -447,21 +448,39 @@ class HeadRunner:
         ops.l2norm_fwd(hb.z, hb.zn, hb.inv, R, Bt)
         ops.linear(hb.zn, wn, hb.logits, R, K, Bt)
 
-    def backward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers, train_last_layer: bool = True):
+    def backward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers, train_last_layer: bool = True, side=None):
+        """``side``: a stream for the weight-gradient products (they feed nothing in backward); each is queued
+        there behind an event that marks its operands ready, with a split-K workspace of its own."""
         R, D, Hd, Bt, K, E = hb.R, self.D, self.hidden, self.bott, self.K, L
         ACC = E.EPI_ACCUM
-        if train_last_layer:   # dW_n = dlogits^T zn, then through weight_norm (g frozen: norm_last_layer)
+        if side is not None and self.ws_side is None:
+            self.ws_side = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, hb.feats.device)
+        main = torch.cuda.current_stream() if side is not None else None
+
+        def on_side(fn):
+            if side is None:
+                return fn(self.ws)
+            ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fn(self.ws_side)
+
+        def dw_last(ws):   # dW_n = dlogits^T zn, then through weight_norm (g frozen: norm_last_layer)
             ops.linear(hb.dlogits, hb.zn, hb.dwn, K, Bt, R, trans_a=True, trans_b=True)
             ops.weightnorm_bwd(hb.dwn, W.f("last_layer.weight_v"), W.f("last_layer.weight_g").view(-1),
                                W.g("last_layer.weight_v"), None, K, Bt, accumulate=True)
+        if train_last_layer:
+            on_side(dw_last)
         hb.dzn.zero_()         # split-K over the K=65536 classes accumulates with atomics
         ops.linear(hb.dlogits, wn, hb.dzn, R, Bt, K, trans_b=True, epilogue=ACC, workspace=self.ws)
         ops.l2norm_bwd(hb.dzn, hb.zn, hb.inv, hb.dz, R, Bt)
-        ops.linear(hb.dz, hb.h2, W.g("mlp.4.weight"), Bt, Hd, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.4.bias"), workspace=self.ws)
+        on_side(lambda ws: ops.linear(hb.dz, hb.h2, W.g("mlp.4.weight"), Bt, Hd, R, trans_a=True, trans_b=True, epilogue=ACC,
+                                      colsum_a=W.g("mlp.4.bias"), workspace=ws))
         ops.linear(hb.dz, W.w("mlp.4.weight"), hb.dh2, R, Hd, Bt, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h2p)
-        ops.linear(hb.dh2, hb.h1, W.g("mlp.2.weight"), Hd, Hd, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.2.bias"), workspace=self.ws)
+        on_side(lambda ws: ops.linear(hb.dh2, hb.h1, W.g("mlp.2.weight"), Hd, Hd, R, trans_a=True, trans_b=True, epilogue=ACC,
+                                      colsum_a=W.g("mlp.2.bias"), workspace=ws))
         ops.linear(hb.dh2, W.w("mlp.2.weight"), hb.dh1, R, Hd, Hd, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h1p)
-        ops.linear(hb.dh1, hb.feats, W.g("mlp.0.weight"), Hd, D, R, trans_a=True, trans_b=True, epilogue=ACC, colsum_a=W.g("mlp.0.bias"), workspace=self.ws)
+        on_side(lambda ws: ops.linear(hb.dh1, hb.feats, W.g("mlp.0.weight"), Hd, D, R, trans_a=True, trans_b=True, epilogue=ACC,
+                                      colsum_a=W.g("mlp.0.bias"), workspace=ws))
         ops.linear(hb.dh1, W.w("mlp.0.weight"), hb.dfeats, R, D, Hd, trans_b=True)
 
 
@@ -638,7 +657,7 @@ class DinoEngine:
                 self.loss.copy_(self._loss_acc / mn); self.center_sum.copy_(self._center_acc)
         if last:
             self.reducer.reduce_tensor(self.center_sum)
-        self.head.backward(self.sH, self.wn_s, self.hb_s, self.train_last_layer)
+        self.head.backward(self.sH, self.wn_s, self.hb_s, self.train_last_layer, side=side)
         if not last:        # more micro-batches follow: gradients keep accumulating locally
             self.vit.backward(self.sW, self.g_stu, self.hb_s.dfeats)
             return
@@ -647,7 +666,11 @@ class DinoEngine:
         if head_names:
             lo = min(a.off[n] for n in head_names)
             hi = max(a.off[n] + _round_up(math.prod(a.specs[n]), PAD) for n in head_names)
-            self.reducer.reduce_range(a.g, lo, hi)
+            if side is not None:          # the head's weight gradients were queued on the side stream
+                with torch.cuda.stream(side):
+                    self.reducer.reduce_range(a.g, lo, hi)
+            else:
+                self.reducer.reduce_range(a.g, lo, hi)
             self._reduced_hi = hi
         else:
             self._reduced_hi = 0
