@@ -10,12 +10,15 @@ bytecode specifies (``vit.pyc@L..``):
                      optimizer + EMA + bf16 refresh is one fused pass and the data-parallel
                      reduction is a few large RCCL calls over contiguous ranges.  Weight-decayed
                      matrices come first, in the order their gradients complete in backward.
-  * ``VitGroup``  -- activations of one crop-resolution group (multi-crop wrapper, row D1).
+  * ``VitGroup``  -- activations of one network pass: the crop groups are ``Segment``s of one
+                     token-concatenated row space (multi-crop wrapper, row D1).
   * ``VitRunner`` -- forward / backward of the encoder as explicit launch sequences.
   * ``DinoEngine`` / ``SupervisedEngine`` -- one training step (rows S1, D1-D5, L1, O1).
 
-Everything is launched on the current stream with static buffers, so a whole step
-can be captured in a hipGraph (``capture=True``).
+The critical path is launched on the caller's current stream with static buffers; work that
+feeds nothing downstream (teacher forward, weight-gradient GEMMs, LayerNorm-gradient finalize)
+goes to one side stream ordered by events.  A step can also be captured in
+a hipGraph (``capture()``, experimental: DESIGN.md section 7); capture keeps everything on one stream.
 """
 from __future__ import annotations
 

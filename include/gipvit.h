@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 1
+#define GV_ABI_VERSION 2
 enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
        GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
