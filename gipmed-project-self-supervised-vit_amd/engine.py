@@ -849,3 +849,38 @@ class SupervisedEngine:
         self.forward_backward(tiles_u8, target)
         self.optimizer_step(lr)
         return self.loss
+
+
+# --------------------------------------------------------------------------- #
+# forward-only encoder: slide-level inference / feature extraction
+# --------------------------------------------------------------------------- #
+class FeatureExtractor:
+    """The encoder run forward-only on the same kernels: per-tile CLS features (what the reference's
+    ``validate()`` writes to ``<slide>_features.pt``, train.py:1281-1282) and, with a classifier head,
+    per-tile logits / positive-class scores (train.py:1186-1343).  Nothing is saved for a backward pass:
+    the group rotates three residual buffers and the fc1 epilogue skips the pre-activation store."""
+
+    def __init__(self, arch="vit_small", img_size=256, batch=256, num_classes=0, mean=MEAN_RON, std=STD_RON, device="cuda:0"):
+        dev = torch.device(device)
+        self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
+        self.D = ARCHS[arch]["embed_dim"]
+        self.mean, self.std = tuple(mean), tuple(std)
+        self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
+        self.W = Weights(self.arena, "")
+        self.vit = VitRunner(arch, img_size, dev)
+        self.grp = VitGroup(arch, [(batch, img_size)], img_size, dev, save=False)
+        self.feats = _empty((batch, self.D), bf16, dev)
+        self.logits = _empty((batch, num_classes), f32, dev) if num_classes else None
+
+    def load_state(self, state: Dict[str, torch.Tensor]):
+        self.arena.load(state)
+        ops.cast_bf16(self.arena.p, self.arena.pb)
+
+    def forward(self, tiles_u8: torch.Tensor):
+        """tiles_u8 [B, img, img, 3] u8 NHWC -> (CLS features bf16 [B, D], logits f32 [B, C] or None)."""
+        assert tiles_u8.shape == (self.B, self.img, self.img, 3) and tiles_u8.dtype == torch.uint8
+        self.vit.forward(self.W, self.grp, tiles_u8, [[(0, 0)]], self.mean, self.std, self.feats)
+        if self.C:
+            ops.small_matmul(self.feats, self.W.f("head.weight"), self.logits, self.B, self.C, self.D, sam=self.D, sak=1, sbk=1, sbn=self.D,
+                             bias=self.W.f("head.bias"))
+        return self.feats, self.logits

@@ -183,6 +183,24 @@ def test_dino_random_crops(dev):
     assert np.array_equal(b._lcrops.cpu().numpy(), ref)
 
 
+@gpu
+def test_feature_extractor_matches_oracle(dev):
+    """Forward-only encoder (slide-level feature extraction): CLS features and logits of ViT-T/16 on 64-px tiles
+    against the oracle's forward."""
+    from gipvit.engine import FeatureExtractor
+    from oracle import vit_oracle as vo
+    p = vo.init_vit("vit_tiny", 64, 2, seed=4)
+    fx = FeatureExtractor(arch="vit_tiny", img_size=64, batch=6, num_classes=2, device=dev)
+    fx.load_state(p)
+    tiles = vo.synth_tiles(6, 64, seed=21)
+    feats, logits = fx.forward(tiles.to(dev))
+    torch.cuda.synchronize()
+    x = vo.normalize_window(tiles, (0, 0, 64))
+    ref_f = vo.vit_features(p, x, "vit_tiny")
+    ref_l = vo.vit_logits(p, x, "vit_tiny")
+    assert _rel(feats, ref_f) < 2e-2 and _rel(logits, ref_l) < 3e-2, (_rel(feats, ref_f), _rel(logits, ref_l))
+
+
 @pytest.mark.graph_experimental
 def test_dino_graph_replay_matches_eager(dev):
     """The captured hipGraph step and the eager step follow the same loss trajectory.
