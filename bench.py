@@ -29,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_TILE = {"c3": 113.83, "c2": 73.93}
+GFLOP_PER_TILE = {("vit_small", "c3"): 113.83, ("vit_small", "c2"): 73.93, ("vit_base", "c3"): 435.56}   # BASELINE.md section 2 / SURVEY 8(a)
 MFMA_BF16_PEAK_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: dense bf16
 
 
@@ -167,8 +167,8 @@ def main():
                        "tiles_per_gpu": args.batch, "global_tiles": args.batch * world, "parallelism": f"dp{world}",
                        "hipgraph": use_graph, "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops)},
             "tiles_per_s_per_gpu": round(tiles_s / world, 2),
-            "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[args.config] / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
-            if args.arch == "vit_small" else None,
+            "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[(args.arch, args.config)] / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
+            if (args.arch, args.config) in GFLOP_PER_TILE else None,
             "final_loss": round(loss, 4),
         }
         out["roofline"] = roofline.dominant_kernel_roofline(lambda: on_main(lambda: eng.step(tiles)), steps=3, vit=eng.vit) if world == 1 else None
