@@ -239,6 +239,10 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
     GV_STAMP(t_kernel0);
 #endif
 
+    // SCHED 20 (lab): a workgroup that walks several items issues the NEXT item's first ring stage before the
+    // epilogue of the current one (the epilogue image then lives in the other stage only)
+    constexpr bool XPF = C::SCHED == 20 && C::NSTAGE == 2 && !ATOMIC;
+    bool prefetched = false;
     for (int it_i = 0, idx = wk.first; it_i < wk.count; ++it_i, idx += wk.stride) {
         const Item it = make_item<C>(g, wk, idx);
         TileSrc<TA, BM, BK, C::NW> srcA;
@@ -270,8 +274,11 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             if (p < C::A_PPW) srcA.issue_one(p, g.lda, p_k0, it.kend, p_st, wave);
             else srcB.issue_one(p - C::A_PPW, g.ldb, p_k0, it.kend, p_st + C::A_BYTES, wave);
         };
+        if (XPF && prefetched) { l_k = 1; l_stage = 1; }      // stage 0 was issued during the previous item's epilogue
+        else {
 #pragma unroll
-        for (int s = 0; s < PD; ++s) issue();
+            for (int s = 0; s < PD; ++s) issue();
+        }
 
         // ---- epilogue geometry (see below) and EARLY PREFETCH of its global operands: the
         // residual / pos / accumulate-into values and the saved pre-activation are loaded into
@@ -280,9 +287,10 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         const int m0 = it.m0 + wm * FM * 16, n0 = it.n0 + wn * FN * 16;
         constexpr int IW = FN * 16;                     // image width (columns of this wave)
         constexpr int STRIDE = IW + 4;                  // f32 row stride, +4 breaks bank conflicts
-        constexpr int ROWS_FIT = (C::LDS / C::NW) / (STRIDE * 4);
+        constexpr int IMG_BYTES = (XPF ? C::STAGE : C::LDS) / C::NW;      // this wave's share of the epilogue image space
+        constexpr int ROWS_FIT = IMG_BYTES / (STRIDE * 4);
         constexpr int IB = ROWS_FIT >= FM * 16 ? FM : (ROWS_FIT >= 32 && FM % 2 == 0 ? 2 : 1);   // 16-row blocks per pass
-        static_assert(16 * STRIDE * 4 <= C::LDS / C::NW, "one 16-row block of the image must fit the wave's share");
+        static_assert(16 * STRIDE * 4 <= IMG_BYTES, "one 16-row block of the image must fit the wave's share");
         constexpr int W = ATOMIC ? 1 : OutVec<OutT>::W;     // columns per lane in the row pass
         constexpr int LPR = IW / W;                          // lanes per image row
         constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;        // image rows per wave-instruction
@@ -411,7 +419,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             GV_STAMP(ts1);
             __builtin_amdgcn_s_barrier();     // everybody's pieces landed; last step's stage is free
             GV_STAMP(ts2);
-            if constexpr (C::SCHED == 0) issue();
+            if constexpr (C::SCHED == 0 || C::SCHED == 20) issue();
             GV_STAMP(ts3);
             GV_LDS char* cur = smem + c_stage * C::STAGE;
             // all fragment reads of the stage are issued up front (KS * (FM + FN) ds_read_b128 /
@@ -438,7 +446,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             __builtin_amdgcn_sched_barrier(0);   // keep every read ahead of the first MFMA
 #endif
             if constexpr (C::SCHED == 1) issue();
-            if constexpr (C::SCHED >= 2) issue_begin();
+            if constexpr (C::SCHED == 2 || C::SCHED == 3) issue_begin();
             constexpr int GROUPS = C::KS * FM;                     // MFMA row groups of FN MFMAs each
             constexpr int PER = (C::GLDS + GROUPS - 1) / GROUPS;   // SCHED 3: pieces per group
 #pragma unroll
@@ -495,7 +503,22 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         // The accumulators go through a per-wave LDS image so that every lane ends up with
         // ROW-CONTIGUOUS columns: bias / residual / aux loads and all stores (and atomics) are
         // then whole 128..256-B row segments instead of 16 scattered 32-B pieces per instruction.
-        GV_LDS float* img = (GV_LDS float*)(smem + wave * (C::LDS / C::NW));
+        if constexpr (XPF) {
+            prefetched = false;
+            if (it_i + 1 < wk.count) {       // every wave is past the ring (barrier above): stage 0 is free for the next item
+                const Item nx = make_item<C>(g, wk, idx + wk.stride);
+                TileSrc<TA, BM, BK, C::NW> nA;
+                TileSrc<TB, BN, BK, C::NW> nB;
+                nA.setup(g.A, g.lda, nx.m0, g.M, wave, lane);
+                nB.setup(g.B, g.ldb, nx.n0, g.N, wave, lane);
+                if (!(g.epi & (1 << 21))) {
+                    nA.issue(g.lda, nx.kbeg, nx.kend, smem, wave);
+                    nB.issue(g.ldb, nx.kbeg, nx.kend, smem + C::A_BYTES, wave);
+                }
+                prefetched = true;
+            }
+        }
+        GV_LDS float* img = (GV_LDS float*)(smem + (XPF ? C::STAGE : 0) + wave * IMG_BYTES);
         float* Cf = (float*)g.C;
         OutT* Cp = (OutT*)g.C;
         bool vec_path = true;

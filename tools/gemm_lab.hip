@@ -59,6 +59,7 @@ template <class C>
 void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void* B, void* Cb, void* ref, float* bias, void* aux,
              float* resid) {
     int shape_idx = -1;
+    const int lab_pm = getenv("LAB_PM") ? atoi(getenv("LAB_PM")) : 0;     // > 0: persistent grid of 256 * WGs/CU * lab_pm workgroups
     for (const auto& sh : shapes) {
         ++shape_idx;
         GemmP p{};
@@ -71,7 +72,7 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
 #endif
         float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
         for (int v = 0; v < (getenv("LAB_FULL_ONLY") ? 1 : 4); ++v) {      // 0 full, 1 no-store, 2 no-store+no-global-load, 3 no-store+no-LDS-read
-            const int pm = 0, order = 0; p.epi = sh.epi | (v >= 1 ? (1 << 20) : 0) | (v == 2 ? (1 << 21) : 0) | (v == 3 ? (1 << 22) : 0);
+            const int pm = lab_pm, order = 0; p.epi = sh.epi | (v >= 1 ? (1 << 20) : 0) | (v == 2 ? (1 << 21) : 0) | (v == 3 ? (1 << 22) : 0);
             for (int round = 0; round < 3; ++round) {
                 float t;
                 if (!sh.ta && !sh.tb) {
@@ -91,11 +92,11 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
             const size_t bytes = (size_t)sh.M * sh.N * (sh.cf32 ? 4 : 2);
             CK(hipMemset(Cb, 0xFF, bytes));
             if (!sh.ta && !sh.tb) {
-                if (sh.epi == GV_EPI_BIAS) run_cfg<C, false, false, bf16, GV_EPI_BIAS>(sh, p, 1, 0, 0);
-                else if (sh.epi == (GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE)) run_cfg<C, false, false, bf16, GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE>(sh, p, 1, 0, 0);
-                else run_cfg<C, false, false, float, GV_EPI_BIAS | GV_EPI_RESID>(sh, p, 1, 0, 0);
-            } else if (!sh.ta && sh.tb) run_cfg<C, false, true, bf16, 0>(sh, p, 1, 0, 0);
-            else run_cfg<C, true, true, float, 0>(sh, p, 1, 0, 0);
+                if (sh.epi == GV_EPI_BIAS) run_cfg<C, false, false, bf16, GV_EPI_BIAS>(sh, p, 1, lab_pm, 0);
+                else if (sh.epi == (GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE)) run_cfg<C, false, false, bf16, GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE>(sh, p, 1, lab_pm, 0);
+                else run_cfg<C, false, false, float, GV_EPI_BIAS | GV_EPI_RESID>(sh, p, 1, lab_pm, 0);
+            } else if (!sh.ta && sh.tb) run_cfg<C, false, true, bf16, 0>(sh, p, 1, lab_pm, 0);
+            else run_cfg<C, true, true, float, 0>(sh, p, 1, lab_pm, 0);
             std::vector<unsigned char> h(bytes);
             CK(hipMemcpy(h.data(), Cb, bytes, hipMemcpyDeviceToHost));
             if ((int)g_ref.size() <= shape_idx) { g_ref.resize(shape_idx + 1); g_ref[shape_idx] = h; }
@@ -115,6 +116,8 @@ void run_all(const char* cname, const std::vector<Shape>& shapes, void* A, void*
 
 int main(int argc, char** argv) {
     const int only_cfg = argc > 1 ? atoi(argv[1]) : -1, only_shape = argc > 2 ? atoi(argv[2]) : -1;
+    const char* cfg_list = getenv("LAB_CFGS");     // e.g. "0,4": run these configurations (in index order) in one process
+    auto want = [&](int c) { if (cfg_list) { char key[8]; snprintf(key, sizeof key, "%d", c); std::string l = std::string(",") + cfg_list + ","; return l.find(std::string(",") + key + ",") != std::string::npos; } return only_cfg < 0 || only_cfg == c; };
     const int T = getenv("LAB_T") ? atoi(getenv("LAB_T")) : 25216;
     std::vector<Shape> all_shapes = {
         {"qkv(NT,bias)", T, 1152, 384, false, false, GV_EPI_BIAS, false},
@@ -141,9 +144,10 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(A, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), nB * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, 4096 * 4)); CK(hipMemset(resid, 0, nC * 4)); CK(hipMemset(aux, 0, nC * 2));
     //            BM   BN  BK WM WN NSTAGE SCHED
-    if (only_cfg < 0 || only_cfg == 0) run_all<Cfg<128, 128, 64, 2, 2, 2, 0>>("128x128 k64 (production)", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 1) run_all<Cfg<256, 256, 32, 2, 4, 4, 10>>("256x256 k32 pingpong", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 2) run_all<Cfg<256, 256, 32, 4, 4, 4, 10>>("256x256 k32 pingpong 16w", shapes, A, B, C, nullptr, bias, aux, resid);
-    if (only_cfg < 0 || only_cfg == 3) run_all<Cfg<256, 128, 32, 2, 4, 4, 10>>("256x128 k32 pingpong", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (want(0)) run_all<Cfg<128, 128, 64, 2, 2, 2, 0>>("128x128 k64 (production)", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (want(1)) run_all<Cfg<256, 256, 32, 2, 4, 4, 10>>("256x256 k32 pingpong", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (want(2)) run_all<Cfg<256, 256, 32, 4, 4, 4, 10>>("256x256 k32 pingpong 16w", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (want(3)) run_all<Cfg<256, 128, 32, 2, 4, 4, 10>>("256x128 k32 pingpong", shapes, A, B, C, nullptr, bias, aux, resid);
+    if (want(4)) run_all<Cfg<128, 128, 64, 2, 2, 2, 20>>("128x128 k64 cross-tile prefetch", shapes, A, B, C, nullptr, bias, aux, resid);
     return 0;
 }
