@@ -114,8 +114,15 @@ int launch(const GemmP& p, hipStream_t s) {
 // C[m][n] += sum_s slab[s][m][n]  (split-K reduce; 16 B per lane, fully coalesced)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long MN4, int S, int N4, long ldc4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (long)gridDim.x * 256) {
+        // four slab loads in flight per thread (the slabs are independent streams; a rolled loop keeps one)
         f32x4 acc = ((const f32x4*)slab)[i];
-        for (int s2 = 1; s2 < S; ++s2) acc += ((const f32x4*)slab)[(long)s2 * MN4 + i];
+        int s2 = 1;
+        for (; s2 + 3 < S; s2 += 4) {
+            const f32x4 a0 = ((const f32x4*)slab)[(long)s2 * MN4 + i], a1 = ((const f32x4*)slab)[(long)(s2 + 1) * MN4 + i];
+            const f32x4 a2 = ((const f32x4*)slab)[(long)(s2 + 2) * MN4 + i], a3 = ((const f32x4*)slab)[(long)(s2 + 3) * MN4 + i];
+            acc += (a0 + a1) + (a2 + a3);
+        }
+        for (; s2 < S; ++s2) acc += ((const f32x4*)slab)[(long)s2 * MN4 + i];
         const long m = i / N4, n4 = i - m * N4;
         f32x4* dst = (f32x4*)C + m * ldc4 + n4;
         *dst = *dst + acc;
