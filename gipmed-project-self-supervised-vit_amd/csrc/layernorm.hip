@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(gv_colsum_finalize
     }
 }
 
-// grid (C/64, 3 outputs, 8 row slices): 144+ blocks instead of 6; slices meet through atomics
+// grid (C/64, 3 outputs, 32 row slices): 576+ blocks instead of 6; slices meet through atomics
 __global__ __launch_bounds__(256) void ln_finalize_kernel(gv_ln_finalize_args a) {
     __shared__ float red[4][64];
     float* out = blockIdx.y == 0 ? a.out0 : blockIdx.y == 1 ? a.out1 : a.out2;
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(gv_ln_finalize_args a)
     if (c < a.C) {
         const float* p = a.partials + (long)blockIdx.y * a.C + c;
         const long stride = 3L * a.C;
+#pragma unroll 4
         for (int b = b0 + grp; b < b1; b += 4) s += p[b * stride];
     }
     red[grp][lane] = s;
@@ -278,7 +279,7 @@ extern "C" int gv_colsum_finalize(const gv_colsum_finalize_args* a, void* stream
 extern "C" int gv_ln_finalize(const gv_ln_finalize_args* a, void* stream) {
     GV_REQUIRE(a && a->partials, GV_E_NULL, "gv_ln_finalize: null pointer");
     GV_REQUIRE(a->C > 0 && a->n_blocks > 0, GV_E_SHAPE, "gv_ln_finalize: bad shape");
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((a->C + 63) / 64, 3, 8), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((a->C + 63) / 64, 3, 32), dim3(256), 0, (hipStream_t)stream, *a);
     GV_LAUNCH_CHECK("gv_ln_finalize");
     return GV_OK;
 }
