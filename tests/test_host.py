@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     """sizeof of every args struct as the C compiler sees it == ctypes' view."""
     from gipvit import _lib
-    names = sorted(s.__name__ for s in _lib.ENTRY_POINTS.values())
+    structs = list(_lib.ENTRY_POINTS.values()) + [_lib.gv_linear_timing_row]
+    names = sorted(s.__name__ for s in structs)
     src = '#include <stdio.h>\n#include "gipvit.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     exe = os.path.join(ROOT, "gpurun_out", "_sizeof_test")
@@ -36,7 +37,7 @@ def test_struct_layout_matches_header():
     r = subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, capture_output=True)
     assert r.returncode == 0, r.stderr
     out = dict(l.split() for l in subprocess.run([exe], capture_output=True, text=True).stdout.splitlines())
-    for st in _lib.ENTRY_POINTS.values():
+    for st in structs:
         assert int(out[st.__name__]) == ctypes.sizeof(st), st.__name__
 
 
@@ -48,6 +49,10 @@ def test_bad_arguments_fail_loudly_without_gpu():
     assert rc == -3 and b"null" in _lib.lib.gv_last_error()
     b = _lib.gv_layernorm_fwd_args(1, 100, 1, 1, 1, 1, 1, 4, 100, 1e-6)
     assert _lib.lib.gv_layernorm_fwd(ctypes.byref(b), None) == -1 and b"192" in _lib.lib.gv_last_error()
+    c = _lib.gv_crop_resize_args(1, 1, 1, 4, 1, 256, 256, 98)      # out_size not a multiple of 4
+    assert _lib.lib.gv_crop_resize(ctypes.byref(c), None) == -1 and b"multiple of 4" in _lib.lib.gv_last_error()
+    rows = (_lib.gv_linear_timing_row * 4)()
+    assert _lib.lib.gv_linear_timing_read(rows, 4) == 0             # nothing recorded: zero rows, no GPU touched
 
 
 def test_arena_layout_and_decay_split():
