@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- tiles/s of one full DINO multi-crop training step (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config c3|c2] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config c3|c2]
 
-One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); kernels are launched eagerly on the
-current HIP stream (the step is GPU-bound: a captured hipGraph measured the same tiles/s).  A step = teacher forward on
+One process per GPU.  Under torchrun (RANK/LOCAL_RANK/WORLD_SIZE in the environment) this process IS one
+rank; started bare with --gpus N > 1 it is only a launcher: it touches no GPU, starts N copies of itself
+with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_ADDR=127.0.0.1/MASTER_PORT set (the reference's
+`torchrun --nproc_per_node=N train.py` pattern, sbatch-ssl.sh:55) and relays rank 0's JSON line.
+Kernels are launched eagerly on the current HIP stream.  A step = teacher forward on
 the 2 global crops + student forward/backward on 2x224 + 8x96 crops of B synthetic 256-px
 NHWC uint8 tiles per GPU (resident in HBM before the timed region) + DINO loss + gradient /
 center all-reduce (RCCL) + AdamW + teacher EMA.  ViT-S/16, K = 65536, bf16 MFMA with f32
@@ -60,6 +63,33 @@ def cpu_baseline(arch, n_local, seconds_budget=25.0):
             "sample": f"{n} oracle steps of B={B} tiles (2x224+{n_local}x96 crops, {arch}, K=65536) after 1 warm-up"}
 
 
+def launch_children(n: int, argv, child=None, timeout=None):
+    """Start n ranks of this script (or of `child`, a command list: tests use a stub) as CHILD processes with the
+    torchrun environment and return (exit code, rank 0's stdout).  The parent never initialises HIP -- nothing is
+    exec'ed from a process that has touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, rc = "", 0
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for pr in procs:
+            rc = rc or pr.wait(timeout=timeout)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()               # the exact children started above, never a pattern
+    return rc, out0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,31 +98,45 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
     ap.add_argument("--config", default="c3", choices=["c3", "c2"])
     ap.add_argument("--arch", default="vit_small")
-    ap.add_argument("--graph", action="store_true", help="EXPERIMENTAL: replay the step from a captured hipGraph (see DESIGN.md section 7: "
-                    "on ROCm 7.2 graph replays were observed to mis-order against stream work; eager launches are exact and equally fast)")
-    ap.add_argument("--no-graph", action="store_true", help="(default) kept for command-line compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-crops", action="store_true", help="cut random-resized crops on the device every step (gv_crop_resize) instead of "
                     "the fixed parity windows of SURVEY 8(d); the default (and the quoted metric) uses the fixed windows")
     ap.add_argument("--trace-loss", action="store_true", help="debug: synchronise and print the loss after every step")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        rc, out0 = launch_children(args.gpus, sys.argv[1:])
+        sys.stdout.write(out0); sys.stdout.flush()
+        raise SystemExit(rc)
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a ONE-GPU box -- every rank uses device 0.  RCCL refuses two
+    # ranks on one device, so the rehearsal's transport is gloo (device tensors staged through the host); everything
+    # else (launcher, shards, ranged reductions, barrier, max-over-ranks timing) is the real path.
+    share = bool(os.environ.get("BENCH_SHARE_GPU"))
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     reducer = None
     # BENCH_FORCE_DIST=1: take the RCCL path even at world size 1 (rehearses process-group set-up, the
     # ranged all-reduces and the barrier on a one-GPU box; the all-reduces then run over a single rank)
     force_dist = bool(os.environ.get("BENCH_FORCE_DIST")) and "RANK" in os.environ
+    rccl_ranks = 1
     if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "gloo" if share else "nccl")      # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         from gipvit.dist import RcclReducer
         reducer = RcclReducer()
         reducer.always = force_dist      # rehearsal: issue the per-block ranges at world size 1 too
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        rccl_ranks = dist.get_world_size()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     from gipvit.engine import DinoEngine
     from gipvit import roofline
@@ -105,17 +149,12 @@ def main():
     eng.load_state(init_vit_state(args.arch, 224, 0, seed=0), init_dino_head_state(eng.D, 65536, seed=1))
     tiles = synth_tiles(args.batch, 256, 1234 + rank, dev)
 
-    use_graph = args.graph and not args.no_graph
-    if use_graph:
-        eng.capture(tiles)
-    if os.environ.get("BENCH_SYNC_AFTER_CAPTURE"):
-        torch.cuda.synchronize()
     if args.random_crops:
         from gipvit.multicrop import MultiCropSampler
         sampler = MultiCropSampler(args.batch, 256, 2, n_local, seed=1234 + rank)
         step0 = lambda: eng.step(tiles, boxes=sampler.sample(dev))
     else:
-        step0 = (lambda: eng.step_graph()) if use_graph else (lambda: eng.step(tiles))
+        step0 = lambda: eng.step(tiles)
 
     # The step's critical path (everything but the teacher forward and the weight-gradient GEMMs, which the
     # engine puts on its side stream) runs on a HIGH-priority stream: its kernels get the CU slots first and
@@ -162,10 +201,10 @@ def main():
             "metric": "tiles/sec/GPU ViT-S/16 DINO (2g+8l crops, 256px) at 1/2/4/8 MI355X",
             "value": round(tiles_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic", "rccl_ranks": rccl_ranks,
             "config": {"workload": f"{args.arch}/16 DINO 2x224+{n_local}x96 crops of 256px NHWC u8 tiles, K=65536 ({args.config})",
                        "tiles_per_gpu": args.batch, "global_tiles": args.batch * world, "parallelism": f"dp{world}",
-                       "hipgraph": use_graph, "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops)},
+                       "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops)},
             "tiles_per_s_per_gpu": round(tiles_s / world, 2),
             "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[(args.arch, args.config)] / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
             if (args.arch, args.config) in GFLOP_PER_TILE else None,

@@ -1,7 +1,8 @@
 """Checkpoint files in the layout the reference writes through timm's CheckpointSaver
 (reference train.py:867-877, 970-973): ``checkpoint-<epoch>.pth.tar``,
 ``last.pth.tar``, ``model_best.pth.tar``, ``recovery-<epoch>-<batch>.pth.tar`` holding
-``{'epoch', 'arch', 'state_dict', 'optimizer', 'version': 2, 'args', 'metric'}``.
+``{'epoch', 'arch', 'state_dict', 'optimizer', 'version': 2, 'args', 'metric', 'state_dict_ema'}``
+(``state_dict_ema`` = timm's key for the ``--model-ema`` copy; a DINO run stores its teacher there, plus ``dino_center``).
 
 Deviation (documented): ``'args'`` is stored as a plain dict, not a pickled Namespace, and
 the optimizer state as tensors, so every file loads with ``torch.load(weights_only=True)``.
@@ -29,7 +30,8 @@ class CheckpointSaver:
             p["optimizer"] = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in optimizer.items()}
         if metric is not None:
             p["metric"] = float(metric)
-        p.update(extra or {})
+        for k, v in (extra or {}).items():       # e.g. 'state_dict_ema' (timm key: the EMA model / DINO teacher), 'dino_center'
+            p[k] = ({n: t.detach().cpu() for n, t in v.items()} if isinstance(v, dict) else (v.detach().cpu() if torch.is_tensor(v) else v))
         return p
 
     def save_checkpoint(self, epoch: int, state_dict: Dict[str, torch.Tensor], optimizer: Optional[dict] = None,
@@ -49,9 +51,9 @@ class CheckpointSaver:
                 os.remove(old)
         return self.best_metric, self.best_epoch
 
-    def save_recovery(self, epoch: int, batch_idx: int, state_dict, optimizer=None):
+    def save_recovery(self, epoch: int, batch_idx: int, state_dict, optimizer=None, extra: Optional[dict] = None):
         path = os.path.join(self.dir, f"recovery-{epoch}-{batch_idx}.pth.tar")
-        torch.save(self._payload(epoch, state_dict, optimizer, None, {"batch_idx": batch_idx}), path)
+        torch.save(self._payload(epoch, state_dict, optimizer, None, dict(extra or {}, batch_idx=batch_idx)), path)
         return path
 
 

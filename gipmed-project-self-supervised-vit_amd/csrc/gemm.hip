@@ -182,6 +182,7 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     GV_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0, GV_E_ALIGN, "gv_linear: lda/ldb must be multiples of 8 elements");
     GV_REQUIRE(gv_aligned(a->A, 16) && gv_aligned(a->B, 16) && gv_aligned(a->C, 16), GV_E_ALIGN, "gv_linear: A/B/C must be 16-byte aligned");
     const int e = a->epilogue;
+    GV_REQUIRE((e & ~GV_EPI_ALL) == 0, GV_E_UNSUPPORTED, "gv_linear: epilogue 0x%x has bits outside the GV_EPI_* mask 0x%x", e, GV_EPI_ALL);
     if (e & GV_EPI_BIAS) GV_REQUIRE(a->bias && gv_aligned(a->bias, 16), GV_E_NULL, "gv_linear: BIAS needs an aligned bias");
     if (e & GV_EPI_RESID) GV_REQUIRE(a->resid && a->ldr % 4 == 0, GV_E_NULL, "gv_linear: RESID needs resid with ldr %% 4 == 0");
     if (e & GV_EPI_DGELU) GV_REQUIRE(a->aux_in && a->ld_aux % 4 == 0, GV_E_NULL, "gv_linear: DGELU needs aux_in");

@@ -3,6 +3,15 @@
 #pragma once
 #include "gv_common.h"
 
+// Tuning-lab switches (ablation bits 20-22 of GemmP::epi, s_memtime stamps, experimental k-loop schedules 10 / 20)
+// exist only in builds made with -DGV_GEMM_LAB (tools/gemm_lab.hip); the production library compiles them out and
+// gv_linear rejects any epilogue bit outside the documented mask.
+#ifdef GV_GEMM_LAB
+#define GV_LAB_BIT(g, bit) (((g).epi & (1 << (bit))) != 0)
+#else
+#define GV_LAB_BIT(g, bit) false
+#endif
+
 namespace gvgemm {
 
 __device__ __attribute__((aligned(256))) unsigned short zero_page[128];   // 256 B of zeros
@@ -207,6 +216,9 @@ __device__ __forceinline__ Item make_item(const GemmP& g, const Walk& w, int idx
     return it;
 }
 
+#if defined(GV_GEMM_STAMPS) && !defined(GV_GEMM_LAB)
+#error "GV_GEMM_STAMPS is a tuning-lab option: build with -DGV_GEMM_LAB"
+#endif
 #ifdef GV_GEMM_STAMPS
 __device__ __forceinline__ unsigned long long gv_stamp() {
     unsigned long long t;
@@ -241,7 +253,12 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
 
     // SCHED 20 (lab): a workgroup that walks several items issues the NEXT item's first ring stage before the
     // epilogue of the current one (the epilogue image then lives in the other stage only)
+    #ifdef GV_GEMM_LAB
     constexpr bool XPF = C::SCHED == 20 && C::NSTAGE == 2 && !ATOMIC;
+#else
+    static_assert(C::SCHED != 10 && C::SCHED != 20, "k-loop schedules 10 / 20 are tuning-lab builds (-DGV_GEMM_LAB)");
+    constexpr bool XPF = false;
+#endif
     bool prefetched = false;
     for (int it_i = 0, idx = wk.first; it_i < wk.count; ++it_i, idx += wk.stride) {
         const Item it = make_item<C>(g, wk, idx);
@@ -252,7 +269,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         // ---- the LDS-DMA ring runs PD k-steps ahead of the MFMAs
         int l_k = 0, l_stage = 0;
         auto issue = [&]() {
-            if (l_k < it.nt && !(g.epi & (1 << 21))) {
+            if (l_k < it.nt && !GV_LAB_BIT(g, 21)) {
                 GV_LDS char* st = smem + l_stage * C::STAGE;
                 const int k0 = it.kbeg + l_k * BK;
                 srcA.issue(g.lda, k0, it.kend, st, wave);
@@ -264,7 +281,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         // the same, one piece at a time (SCHED >= 2 spreads a step's pieces between its MFMAs)
         bool p_live = false; GV_LDS char* p_st = smem; int p_k0 = 0;
         auto issue_begin = [&]() {
-            p_live = l_k < it.nt && !(g.epi & (1 << 21));
+            p_live = l_k < it.nt && !GV_LAB_BIT(g, 21);
             p_st = smem + l_stage * C::STAGE; p_k0 = it.kbeg + l_k * BK;
             ++l_k;
             l_stage = (l_stage + 1 == NSTAGE) ? 0 : l_stage + 1;
@@ -353,6 +370,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
         GV_STAMP(t_loop0);
 #endif
         int c_stage = 0;
+#ifdef GV_GEMM_LAB
         if constexpr (C::SCHED == 10) {
             // ---- PING-PONG k-loop (lab): the workgroup's two halves of wave rows (SIMD partners: waves w and w + NW/2)
             // alternate roles every half step: while one group issues the LDS-DMA of step t + PD and reads its
@@ -406,6 +424,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             }
             if (grp == 0) __builtin_amdgcn_s_barrier();
         } else
+#endif
         for (int t = 0; t < it.nt; ++t) {
             GV_STAMP(ts0);
             // this step's pieces (mine) landed: everything but the younger in-flight steps
@@ -426,7 +445,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
             // tr reads); the MFMAs then run back-to-back behind the compiler's counted lgkmcnt(N)
             // instead of exposing the LDS latency once per small read group.
             bf16x8 fa[C::KS][FM], fb[C::KS][FN];
-            if (g.epi & (1 << 22)) {     // lab ablation: fragments from registers, no LDS reads
+            if (GV_LAB_BIT(g, 22)) {     // lab ablation: fragments from registers, no LDS reads
 #pragma unroll
                 for (int ks = 0; ks < C::KS; ++ks) {
 #pragma unroll
@@ -511,7 +530,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
                 TileSrc<TB, BN, BK, C::NW> nB;
                 nA.setup(g.A, g.lda, nx.m0, g.M, wave, lane);
                 nB.setup(g.B, g.ldb, nx.n0, g.N, wave, lane);
-                if (!(g.epi & (1 << 21))) {
+                if (!GV_LAB_BIT(g, 21)) {
                     nA.issue(g.lda, nx.kbeg, nx.kend, smem, wave);
                     nB.issue(g.ldb, nx.kbeg, nx.kend, smem + C::A_BYTES, wave);
                 }
@@ -595,7 +614,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
                                 }
                                 v[q] += r[0]; v[q + 1] += r[1]; v[q + 2] += r[2]; v[q + 3] += r[3];
                             }
-                            if (g.epi & (1 << 20)) { asm volatile("" ::"v"(v[0]), "v"(v[W - 1])); }   // lab ablation: no store
+                            if (GV_LAB_BIT(g, 20)) { asm volatile("" ::"v"(v[0]), "v"(v[W - 1])); }   // lab ablation: no store
                             else if (ok) {
                                 if constexpr (W == 8) *(bf16x8*)(Cp + orow * g.ldc + n) = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
                                 else store4<OutT>(Cp + orow * g.ldc + n, v);

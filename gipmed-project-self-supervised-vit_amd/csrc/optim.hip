@@ -27,12 +27,15 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 g = ((const f32x4*)a.grad)[i] * gscale;
         f32x4 p = ((f32x4*)a.p)[i], m = ((f32x4*)a.m)[i], v = ((f32x4*)a.v)[i];
-        if (a.mode == 0) {
+        if (a.mode == 3) {
+            // frozen range (no gradient: the optimizer skips the parameter); only the EMA below runs
+        } else if (a.mode == 0) {
             p *= decay;
         } else {
             g += p * a.weight_decay;                        // L2 decay rides on the gradient
         }
-        if (a.mode == 2) {                                  // SGD, Nesterov momentum (torch.optim.SGD semantics)
+        if (a.mode == 3) {
+        } else if (a.mode == 2) {                                  // SGD, Nesterov momentum (torch.optim.SGD semantics)
             m = m * a.beta1 + g;
             p -= (g + m * a.beta1) * a.lr;
         } else {
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) p[j] -= step * m[j] / (sqrtf(v[j]) * inv_sqrt_bc2 + a.eps);
         }
-        ((f32x4*)a.p)[i] = p; ((f32x4*)a.m)[i] = m; ((f32x4*)a.v)[i] = v;
+        if (a.mode != 3) { ((f32x4*)a.p)[i] = p; ((f32x4*)a.m)[i] = m; ((f32x4*)a.v)[i] = v; }
         if (a.p_bf16) ((bf16x4*)a.p_bf16)[i] = bf16x4{(bf16)p[0], (bf16)p[1], (bf16)p[2], (bf16)p[3]};
         if (a.teacher) {
             f32x4 t = ((f32x4*)a.teacher)[i] * a.teacher_momentum + p * om;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
 
 extern "C" int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream) {
     GV_REQUIRE(a && a->p && a->grad && a->m && a->v, GV_E_NULL, "gv_adamw_ema: null pointer");
-    GV_REQUIRE(a->mode >= 0 && a->mode <= 2, GV_E_UNSUPPORTED, "gv_adamw_ema: mode must be 0 (AdamW), 1 (Adam+L2) or 2 (SGD Nesterov)");
+    GV_REQUIRE(a->mode >= 0 && a->mode <= 3, GV_E_UNSUPPORTED, "gv_adamw_ema: mode must be 0 (AdamW), 1 (Adam+L2), 2 (SGD Nesterov) or 3 (frozen: EMA only)");
     GV_REQUIRE(a->n > 0 && a->n % 4 == 0, GV_E_SHAPE, "gv_adamw_ema: n=%ld must be a positive multiple of 4 (pad the arena)", (long)a->n);
     GV_REQUIRE(gv_aligned(a->p, 16) && gv_aligned(a->grad, 16) && gv_aligned(a->m, 16) && gv_aligned(a->v, 16), GV_E_ALIGN,
                "gv_adamw_ema: buffers must be 16-byte aligned");

@@ -17,8 +17,7 @@ bytecode specifies (``vit.pyc@L..``):
 
 The critical path is launched on the caller's current stream with static buffers; work that
 feeds nothing downstream (teacher forward, weight-gradient GEMMs, LayerNorm-gradient finalize)
-goes to one side stream ordered by events.  A step can also be captured in
-a hipGraph (``capture()``, experimental: DESIGN.md section 7); capture keeps everything on one stream.
+goes to one side stream ordered by events.
 """
 from __future__ import annotations
 
@@ -130,9 +129,14 @@ class Arena:
         o = self.off[name]
         return buf[o:o + math.prod(shape)].view(shape)
 
-    def load(self, state: Dict[str, torch.Tensor]):
+    def span(self, name: str) -> Tuple[int, int]:
+        """[lo, hi) of one parameter in the flat buffers, padding included."""
+        return self.off[name], self.off[name] + _round_up(math.prod(self.specs[name]), PAD)
+
+    def load(self, state: Dict[str, torch.Tensor], buf: Optional[torch.Tensor] = None):
+        buf = self.p if buf is None else buf
         for n in self.specs:
-            self.view(self.p, n).copy_(state[n].to(f32))
+            self.view(buf, n).copy_(state[n].to(f32))
 
     def state_dict(self, buf=None, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
         buf = self.p if buf is None else buf
@@ -319,7 +323,7 @@ class VitRunner:
         # fork(): side waits for what main has enqueued; join(ev): main waits for a side event
         # before it overwrites a buffer a dW product still reads (gb / dh / dqkv).
         main = torch.cuda.current_stream() if xl.is_cuda else None
-        side = self.side if (main is not None and self.side is not None and not torch.cuda.is_current_stream_capturing()) else None
+        side = self.side if (main is not None and self.side is not None) else None
         evs = self._events
         n_ev = [0]
 
@@ -552,8 +556,6 @@ class DinoEngine:
         self._n_micro = 1
         if torch.device(device).type == "cuda":
             self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
-        self.graph = None
-        self._static_tiles = None
         # contiguous arena range of every block's weight-decayed matrices (arena order = backward order)
         self._block_range = {}
         for i in range(ARCHS[arch]["depth"]):
@@ -567,6 +569,16 @@ class DinoEngine:
         st.update({"head." + k: v for k, v in head.items()})
         self.arena.load(st)
         self.arena.t.copy_(self.arena.p)            # teacher starts as a copy of the student
+        self.refresh_bf16()
+
+    def load_teacher_state(self, backbone: Dict[str, torch.Tensor], head: Dict[str, torch.Tensor], center: Optional[torch.Tensor] = None):
+        """Restore the EMA teacher (and the centre) of a saved run: without it a resumed run would restart the
+        teacher from the student while the momentum schedule is already near 1."""
+        st = {"backbone." + k: v for k, v in backbone.items()}
+        st.update({"head." + k: v for k, v in head.items()})
+        self.arena.load(st, self.arena.t)
+        if center is not None:
+            self.center.copy_(center.to(self.center.device, f32).view(-1))
         self.refresh_bf16()
 
     def refresh_bf16(self):
@@ -591,16 +603,15 @@ class DinoEngine:
     # ---- the step --------------------------------------------------------------------
     def set_hyper(self, lr=None, wd=None, momentum_teacher=None, teacher_temp=None, n_micro: int = 1):
         """Put the per-step schedule values into the device hyper vector with a tiny stream-ordered
-        kernel whose ARGUMENTS carry them (outside any captured graph).  Not a memcpy: the host
-        runs many graph replays ahead of the GPU, and a pinned staging buffer would be rewritten
-        (or, on an idle queue, copied out of order) before the queued steps consumed it."""
+        kernel whose ARGUMENTS carry them.  Not a memcpy: the host runs several steps ahead of the
+        GPU, and a pinned staging buffer would be rewritten before the queued steps consumed it."""
         self.t += 1
         vals = [0.0] * L.HYP_COUNT
         vals[L.HYP_LR] = self.lr if lr is None else lr
         vals[L.HYP_WD] = self.wd if wd is None else wd
         vals[L.HYP_BC1] = 1.0 - self.betas[0] ** self.t
         vals[L.HYP_BC2] = 1.0 - self.betas[1] ** self.t
-        vals[L.HYP_TEACHER_MOM] = self.m_teacher if momentum_teacher is None else momentum_teacher
+        vals[L.HYP_TEACHER_MOM] = self._cur_mom = self.m_teacher if momentum_teacher is None else momentum_teacher
         vals[L.HYP_GRAD_SCALE] = 1.0 / (self.reducer.world * n_micro)
         vals[L.HYP_TEACHER_TEMP] = self.tt if teacher_temp is None else teacher_temp
         vals[L.HYP_STUDENT_TEMP] = self.ts
@@ -634,7 +645,7 @@ class DinoEngine:
                 s_src.append(self._lcrops); s_win.append([(0, 0)])
         # the teacher's forward shares nothing with the student's until the loss: it runs on the
         # side stream beside the student forward (fills the tail of each other's kernels)
-        side = self.vit.side if (tiles_u8.is_cuda and not torch.cuda.is_current_stream_capturing()) else None
+        side = self.vit.side if tiles_u8.is_cuda else None
         if side is not None:
             main = torch.cuda.current_stream()
             self._ev_fork.record(main); side.wait_event(self._ev_fork)
@@ -697,8 +708,18 @@ class DinoEngine:
             ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
         kw = dict(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=max(self.t, 1),
                   clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None, hyper=self.hyper)
-        sl = slice(0, a.n_decay)
-        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], a.t[sl], a.tb[sl], a.n_decay, weight_decay=1.0, **kw)
+        lo = 0
+        if not self.train_last_layer:
+            # the head's last layer is frozen for the first epochs (DINO cancel_gradients_last_layer sets its grad to
+            # None, so the optimizer SKIPS it: no decay, no moment update) -- only the teacher EMA runs over its range
+            lo, hi = a.span("head.last_layer.weight_v")
+            assert lo == 0, "the last layer opens the arena (backward-completion order)"
+            sl = slice(lo, hi)
+            ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], a.t[sl], a.tb[sl], hi - lo, lr=0.0, beta1=self.betas[0],
+                          beta2=self.betas[1], eps=self.eps, weight_decay=0.0, step=1, hyper=self.hyper, mode=3)
+            lo = hi
+        sl = slice(lo, a.n_decay)
+        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], a.t[sl], a.tb[sl], a.n_decay - lo, weight_decay=1.0, **kw)
         if a.n > a.n_decay:   # biases / LN / pos / cls: same schedules, weight-decay multiplier 0
             sl = slice(a.n_decay, a.n)
             ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], a.t[sl], a.tb[sl], a.n - a.n_decay, weight_decay=0.0, **kw)
@@ -731,39 +752,6 @@ class DinoEngine:
         self.optimizer_step()
         return self.loss
 
-    # ---- hipGraph capture of the whole step (static buffers, device-resident schedules)
-    def capture(self, tiles_u8: torch.Tensor):
-        self._static_tiles = tiles_u8.clone()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):   # warm up on the side stream (lazy attribute setup, RCCL init)
-            self.forward_backward(self._static_tiles)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.forward_backward(self._static_tiles)
-            self.optimizer_step()
-
-    def step_graph(self, tiles_u8: Optional[torch.Tensor] = None, sync: bool = True, **sched) -> torch.Tensor:
-        """Replay the captured step, then (default) ``torch.cuda.synchronize()`` -- the same
-        device-wide sync the reference's loop issues after every step (train.py:1083).
-
-        This is a correctness requirement on ROCm 7.2 / MI355X, not a convenience (measurements
-        in DESIGN.md section 7, tools/replay_cfg.py): work launched by hipGraphLaunch is not
-        reliably covered by STREAM- or EVENT-level ordering -- a stream sync can return while the
-        replay's tail kernels still run (a loss read then sees a partial atomic sum), and replays
-        queued back-to-back behind a device sync overlap (optimizer of step k racing the
-        gradient zeroing of step k+1: wrong losses, NaN).  A device-wide sync after each replay
-        has been exact in every experiment and costs < 0.2 % at 25 ms / step."""
-        if tiles_u8 is not None:
-            self._static_tiles.copy_(tiles_u8, non_blocking=True)
-        self.set_hyper(**sched)
-        self.graph.replay()
-        if sync:
-            torch.cuda.synchronize()
-        return self.loss
-
 
 # --------------------------------------------------------------------------- #
 # supervised single-crop step (reference train.py:1044-1078; BASELINE config 1)
@@ -773,14 +761,18 @@ class SupervisedEngine:
 
     def __init__(self, arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999),
                  eps=1e-8, smoothing=0.1, clip_grad: float = 0.0, mean=MEAN_RON, std=STD_RON, device="cuda:0", reducer=None,
-                 opt: str = "adamw", momentum: float = 0.9, train_backbone: bool = True):
+                 opt: str = "adamw", momentum: float = 0.9, train_backbone: bool = True, model_ema_decay: Optional[float] = None):
         dev = torch.device(device)
         self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
         D = ARCHS[arch]["embed_dim"]
         self.D = D
         self.mean, self.std = tuple(mean), tuple(std)
-        self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
+        # --model-ema (train.py:615-622, ModelEmaV2): the EMA copy lives in the arena's teacher slot and is
+        # updated by the same fused optimizer pass (train.py:1080-1081)
+        self.ema_decay = model_ema_decay
+        self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=model_ema_decay is not None)
         self.W = Weights(self.arena, "")
+        self.Wema = Weights(self.arena, "", teacher=True) if model_ema_decay is not None else None
         self.vit = VitRunner(arch, img_size, dev)
         self.grp = VitGroup(arch, [(batch, img_size)], img_size, dev, save=True)
         e = lambda shape, dt: _empty(shape, dt, dev)
@@ -800,19 +792,25 @@ class SupervisedEngine:
             self.betas = (momentum, betas[1])
         self.train_backbone = train_backbone      # False = --no-grad head-only fine-tune (train.py:497-503)
 
-    def load_state(self, state: Dict[str, torch.Tensor]):
+    def load_state(self, state: Dict[str, torch.Tensor], ema_state: Optional[Dict[str, torch.Tensor]] = None):
         self.arena.load(state)
         ops.cast_bf16(self.arena.p, self.arena.pb)
+        if self.arena.t is not None:       # ModelEmaV2 starts as a deep copy of the model; a resumed run restores it
+            if ema_state is not None:
+                self.arena.load(ema_state, self.arena.t)
+            else:
+                self.arena.t.copy_(self.arena.p)
+            ops.cast_bf16(self.arena.t, self.arena.tb)
 
-    def state_dict(self):
-        return self.arena.state_dict()
+    def state_dict(self, ema: bool = False):
+        return self.arena.state_dict(self.arena.t if ema else None)
 
     def grads(self):
         return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
 
-    def forward(self, tiles_u8):
-        """Inference / features: returns (logits f32 [B,C], CLS features bf16 [B,D])."""
-        B, C, D, W = self.B, self.C, self.D, self.W
+    def forward(self, tiles_u8, ema: bool = False):
+        """Inference / features: returns (logits f32 [B,C], CLS features bf16 [B,D]); ``ema``: with the EMA weights."""
+        B, C, D, W = self.B, self.C, self.D, (self.Wema if ema else self.W)
         self.vit.forward(W, self.grp, tiles_u8, [[(0, 0)]], self.mean, self.std, self.feats)
         ops.small_matmul(self.feats, W.f("head.weight"), self.logits, B, C, D, sam=D, sak=1, sbk=1, sbn=D, bias=W.f("head.bias"))
         return self.logits, self.feats
@@ -838,11 +836,18 @@ class SupervisedEngine:
             ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
         kw = dict(lr=self.lr if lr is None else lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=self.t,
                   grad_scale=1.0 / self.reducer.world, clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None,
-                  mode=self.opt_mode)
-        sl = slice(0, a.n_decay)
-        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], None, None, a.n_decay, weight_decay=self.wd, **kw)
-        sl = slice(a.n_decay, a.n)
-        ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], None, None, a.n - a.n_decay, weight_decay=0.0, **kw)
+                  mode=self.opt_mode, teacher_momentum=self.ema_decay or 0.0)
+        tt = (lambda sl: (a.t[sl], a.tb[sl])) if a.t is not None else (lambda sl: (None, None))
+        if self.train_backbone:
+            ranges = [(0, a.n_decay, self.wd), (a.n_decay, a.n, 0.0)]
+        else:
+            # --no-grad (train.py:497-503): the encoder has requires_grad=False, so the optimizer never sees it -- no
+            # weight decay, no moments; only the classifier's two tensors are stepped (the EMA of the frozen part
+            # stays equal to the model it was copied from)
+            ranges = [a.span("head.weight") + (self.wd,), a.span("head.bias") + (0.0,)]
+        for lo, hi, wd in ranges:
+            sl = slice(lo, hi)
+            ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], *tt(sl), hi - lo, weight_decay=wd, **kw)
 
     def step(self, tiles_u8, target, lr=None):
         assert tiles_u8.dtype == torch.uint8 and target.dtype == torch.int64
@@ -858,19 +863,28 @@ class FeatureExtractor:
     """The encoder run forward-only on the same kernels: per-tile CLS features (what the reference's
     ``validate()`` writes to ``<slide>_features.pt``, train.py:1281-1282) and, with a classifier head,
     per-tile logits / positive-class scores (train.py:1186-1343).  Nothing is saved for a backward pass:
-    the group rotates three residual buffers and the fc1 epilogue skips the pre-activation store."""
+    the group rotates three residual buffers and the fc1 epilogue skips the pre-activation store.
 
-    def __init__(self, arch="vit_small", img_size=256, batch=256, num_classes=0, mean=MEAN_RON, std=STD_RON, device="cuda:0"):
+    ``weights``: a ``Weights`` view of another engine's arena (student, EMA or DINO teacher) -- the
+    extractor then evaluates those live parameters instead of owning a copy (validation between epochs)."""
+
+    def __init__(self, arch="vit_small", img_size=256, batch=256, num_classes=0, mean=MEAN_RON, std=STD_RON, device="cuda:0",
+                 weights: Optional[Weights] = None):
         dev = torch.device(device)
         self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
         self.D = ARCHS[arch]["embed_dim"]
         self.mean, self.std = tuple(mean), tuple(std)
-        self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
-        self.W = Weights(self.arena, "")
+        if weights is None:
+            self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
+            self.W = Weights(self.arena, "")
+        else:
+            self.arena, self.W = weights.a, weights
         self.vit = VitRunner(arch, img_size, dev)
+        self.vit.side = None                       # a forward-only pass has nothing to put on a side stream
         self.grp = VitGroup(arch, [(batch, img_size)], img_size, dev, save=False)
         self.feats = _empty((batch, self.D), bf16, dev)
         self.logits = _empty((batch, num_classes), f32, dev) if num_classes else None
+        self._pad = None
 
     def load_state(self, state: Dict[str, torch.Tensor]):
         self.arena.load(state)
@@ -884,3 +898,23 @@ class FeatureExtractor:
             ops.small_matmul(self.feats, self.W.f("head.weight"), self.logits, self.B, self.C, self.D, sam=self.D, sak=1, sbk=1, sbn=self.D,
                              bias=self.W.f("head.bias"))
         return self.feats, self.logits
+
+    def run(self, tiles_u8: torch.Tensor):
+        """Any number of tiles (one chunk of a slide, datasets.py:699-700 ``tiles_per_iter``): batches of B, the last
+        one padded.  -> (features f32 [n, D], logits f32 [n, C] or None), device tensors owned by the caller."""
+        n = tiles_u8.shape[0]
+        feats = torch.empty(n, self.D, dtype=f32, device=self.dev)
+        logits = torch.empty(n, self.C, dtype=f32, device=self.dev) if self.C else None
+        for lo in range(0, n, self.B):
+            hi = min(n, lo + self.B)
+            part = tiles_u8[lo:hi]
+            if hi - lo < self.B:
+                if self._pad is None:
+                    self._pad = torch.zeros(self.B, self.img, self.img, 3, dtype=torch.uint8, device=self.dev)
+                self._pad[: hi - lo].copy_(part)
+                part = self._pad
+            f, l = self.forward(part)
+            feats[lo:hi].copy_(f[: hi - lo])
+            if logits is not None:
+                logits[lo:hi].copy_(l[: hi - lo])
+        return feats, logits

@@ -147,7 +147,8 @@ int gv_colsum(const gv_colsum_args* a, void* stream);
  *    ACCUM: v += C[m,n] (f32 out only);  then C[m,n] = v (bf16 or f32).       */
 enum {
     GV_EPI_BIAS = 1, GV_EPI_GELU = 2, GV_EPI_RESID = 4, GV_EPI_DGELU = 8,
-    GV_EPI_ACCUM = 16, GV_EPI_POS = 32, GV_EPI_SAVE_PRE = 64
+    GV_EPI_ACCUM = 16, GV_EPI_POS = 32, GV_EPI_SAVE_PRE = 64,
+    GV_EPI_ALL = 127      /* any other bit is rejected with GV_E_UNSUPPORTED */
 };
 typedef struct {
     const void* A; const void* B; void* C;
@@ -316,7 +317,10 @@ typedef struct {
     /* 0 = AdamW (decoupled decay, torch.optim.AdamW); 1 = Adam with L2 decay folded into the
      * gradient (timm --opt adam, the documented runs: train_instruct.txt:23); 2 = SGD with
      * Nesterov momentum beta1 and L2 decay (timm --opt sgd, the reference default, train.py:161);
-     * `m` is the momentum buffer, `v` is unused in mode 2.                                   */
+     * `m` is the momentum buffer, `v` is unused in mode 2; 3 = frozen range: p, m, v are left
+     * untouched (a parameter without a gradient is skipped by torch optimizers: reference
+     * train.py:497-503 --no-grad, DINO's frozen last layer) and only the teacher EMA / bf16
+     * refresh run.                                                                           */
     int32_t mode;
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);

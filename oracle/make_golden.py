@@ -39,8 +39,44 @@ def dino_tiny():
                         g_last=grads["head.last_layer.weight_v"].numpy()[:4, :32])
 
 
+def dino_curve_schedule(step: int, steps: int = 100, per_epoch: int = 25, B: int = 8):
+    """The DINO recipe's per-step values (paper / SURVEY row D5), restated independently of the product's sched.py:
+    lr = 5e-4 * B / 256 with a one-epoch linear warm-up from 1e-6 then cosine to 1e-6; weight decay cosine 0.04 -> 0.4;
+    teacher momentum cosine 0.996 -> 1; teacher temperature 0.04 -> 0.07 linearly over the first 2 epochs; the head's
+    last layer frozen during epoch 0."""
+    import math
+    cos = lambda a, b, t, n: b + 0.5 * (a - b) * (1 + math.cos(math.pi * min(t, n - 1) / (n - 1)))
+    epoch, peak, floor = step // per_epoch, 5e-4 * B / 256.0, 1e-6
+    t = step / per_epoch                                            # fractional epoch (schedule stepped per update)
+    epochs = steps // per_epoch
+    lr = floor + (peak - floor) * t / 1.0 if t < 1.0 else floor + 0.5 * (peak - floor) * (1 + math.cos(math.pi * min(t, epochs) / epochs))
+    tt = [0.04, 0.07][min(epoch, 1)] if epoch < 2 else 0.07        # np.linspace(0.04, 0.07, 2) then 0.07
+    return dict(lr=lr, wd=cos(0.04, 0.4, step, steps), momentum_teacher=cos(0.996, 1.0, step, steps), teacher_temp=tt,
+                train_last_layer=epoch >= 1)
+
+
+def dino_tiny_curve(steps=100):
+    """100 DINO steps (the length north_star gates at 1e-3): ViT-T, 2x224 + 8x96 crops of eight fresh 256-px tiles per
+    step, K = 4096, clip 3.0, the recipe's schedules above.  Keeps the loss curve, the centre and slices of the
+    student / teacher weights at the end."""
+    orc = so.DinoOracle(arch="vit_tiny", img_size=224, out_dim=4096, seed=0, clip_grad=3.0)
+    curve, gnorm = [], []
+    for t in range(steps):
+        r = orc.step(vo.synth_tiles(8, 256, seed=5000 + t), **dino_curve_schedule(t, steps))
+        curve.append(r["loss"]); gnorm.append(r["grad_norm"])
+    np.savez_compressed(os.path.join(OUT, "dino_tiny_curve.npz"), curve=np.array(curve), grad_norm=np.array(gnorm),
+                        center=orc.center.numpy()[0, :512],
+                        s_qkv0=orc.p["blocks.0.attn.qkv.weight"].numpy()[:8, :32], t_qkv0=orc.tp["blocks.0.attn.qkv.weight"].numpy()[:8, :32],
+                        s_fc2_11=orc.p["blocks.11.mlp.fc2.weight"].numpy()[:8, :32], t_fc2_11=orc.tp["blocks.11.mlp.fc2.weight"].numpy()[:8, :32],
+                        s_last=orc.hp["last_layer.weight_v"].numpy()[:8, :32], t_last=orc.thp["last_layer.weight_v"].numpy()[:8, :32],
+                        s_pos=orc.p["pos_embed"].numpy()[0, :4, :32], s_mlp4=orc.hp["mlp.4.weight"].numpy()[:8, :32],
+                        init_qkv0=vo.init_vit("vit_tiny", 224, 0, 0)["blocks.0.attn.qkv.weight"].numpy()[:8, :32])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    supervised_c1()
-    dino_tiny()
+    import sys
+    which = sys.argv[1:] or ["supervised_c1", "dino_tiny", "dino_tiny_curve"]
+    for name in which:
+        globals()[name]()
     print("wrote", sorted(os.listdir(OUT)))

@@ -52,28 +52,34 @@ class DinoOracle:
     def crops(self, tiles_u8):
         return [vo.normalize_window(tiles_u8, w, dtype=self.dtype) for w in self.wins]
 
-    def forward_backward(self, tiles_u8):
+    def forward_backward(self, tiles_u8, teacher_temp=None):
         crops = self.crops(tiles_u8)
         V, G = len(crops), self.n_global
         with torch.no_grad():
             t_out = vo.multicrop_forward(self.tp, self.thp, crops[:G], self.arch)
         sp, shp = _leafify(self.p), _leafify(self.hp)
         s_out = vo.multicrop_forward(sp, shp, crops, self.arch)
-        loss, bsum = vo.dino_loss(s_out, t_out, self.center, V, G, self.ts, self.tt)
+        loss, bsum = vo.dino_loss(s_out, t_out, self.center, V, G, self.ts, self.tt if teacher_temp is None else teacher_temp)
         loss.backward()
         grads = {**{"backbone." + k: v.grad for k, v in sp.items()},
                  **{"head." + k: v.grad for k, v in shp.items()}}
         return loss.detach(), grads, s_out.detach(), t_out, bsum
 
-    def step(self, tiles_u8, lr=None, wd=None):
-        loss, grads, s_out, t_out, bsum = self.forward_backward(tiles_u8)
+    def step(self, tiles_u8, lr=None, wd=None, momentum_teacher=None, teacher_temp=None, train_last_layer=True):
+        """One DINO step with this step's schedule values (cosine wd / teacher momentum, teacher-temperature
+        warm-up, last layer frozen during the first epochs).  A frozen last layer has NO gradient (DINO
+        cancel_gradients_last_layer: p.grad = None), so it is left out of the clip norm and skipped by AdamW."""
+        loss, grads, s_out, t_out, bsum = self.forward_backward(tiles_u8, teacher_temp)
+        if not train_last_layer:
+            grads["head.last_layer.weight_v"] = None
         gn = grad_norm(grads)
         if self.clip is not None and gn > self.clip:
             c = self.clip / (gn + 1e-6)
             grads = {k: (g * c if g is not None else None) for k, g in grads.items()}
         self.opt.step(grads, lr, wd)
-        vo.ema_update(self.tp, self.p, self.m)
-        vo.ema_update(self.thp, self.hp, self.m)
+        m = self.m if momentum_teacher is None else momentum_teacher
+        vo.ema_update(self.tp, self.p, m)
+        vo.ema_update(self.thp, self.hp, m)
         self.center = vo.update_center(self.center, bsum, t_out.shape[0], self.cm)
         return dict(loss=float(loss), grad_norm=gn, student_out=s_out, teacher_out=t_out)
 

@@ -292,7 +292,8 @@ def multicrop_forward(p, hp, crops: Sequence[torch.Tensor], arch: str):
 def no_weight_decay(name: str, t: torch.Tensor) -> bool:
     """timm create_optimizer_v2 filter: 1-D params, *.bias and
     pos_embed / cls_token get weight decay 0."""
-    return t.ndim <= 1 or name.endswith(".bias") or name in ("pos_embed", "cls_token") \
+    base = name.split(".", 1)[1] if name.startswith(("backbone.", "head.")) else name   # DinoOracle prefixes its two modules
+    return t.ndim <= 1 or name.endswith(".bias") or base in ("pos_embed", "cls_token") \
         or name.endswith("weight_g")
 
 

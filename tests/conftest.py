@@ -10,7 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
-    config.addinivalue_line("markers", "graph_experimental: hipGraph replay path, not part of the gpu suite (DESIGN.md section 7)")
 
 
 @pytest.fixture(scope="session")

@@ -55,7 +55,7 @@ def test_supervised_step_parity(dev):
     for i in range(5):
         r = orc.step(tiles, tgt)
         l = eng.step(tiles.to(dev), tgt.to(dev))
-        assert abs(float(l) - r["loss"]) <= 1e-2, (i, float(l), r["loss"])   # lr 1e-3 Adam: chaotic regime; the golden curve at 1e-4 holds 1e-3
+        assert abs(float(l) - r["loss"]) <= 5e-3, (i, float(l), r["loss"])   # lr 1e-3 on 8 tiles: Adam's sign-like first updates amplify bf16 noise; the 100-step curves hold 1e-3
 
 
 @gpu
@@ -87,29 +87,26 @@ def test_dino_step_parity(dev, n_local):
     for i in range(3):
         r = orc.step(tiles)
         l = eng.step(tiles.to(dev))
-        assert abs(float(l) - r["loss"]) <= 2e-2, (i, float(l), r["loss"])
+        assert abs(float(l) - r["loss"]) <= 5e-3, (i, float(l), r["loss"])
     torch.cuda.synchronize()
     assert _rel(eng.center, orc.center[0]) < 1e-2
     sd, td = eng.backbone_state_dict(), eng.backbone_state_dict(teacher=True)
     for k in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "pos_embed", "norm.weight"):
-        assert _rel(sd[k], orc.p[k]) < 2e-2, k
+        assert _rel(sd[k], orc.p[k]) < 5e-3, k
         assert _rel(td[k], orc.tp[k]) < 1e-3, k
 
 
 @gpu
-@pytest.mark.parametrize("arch,n_local,B", [("vit_small", 0, 2), ("vit_small", 8, 2), ("vit_base", 8, 1)])
-def test_dino_forward_backward_parity_configs(dev, arch, n_local, B):
+@pytest.mark.parametrize("arch,n_local,B,K", [("vit_small", 0, 8, 2048), ("vit_small", 8, 8, 2048), ("vit_base", 8, 8, 2048),
+                                              ("vit_small", 8, 4, 65536)])
+def test_dino_forward_backward_parity_configs(dev, arch, n_local, B, K):
     """BASELINE configs 2, 3 and 5 at their real widths (ViT-S/16 with 2 global crops only, ViT-S/16 and
-    ViT-B/16 with 2 global + 8 local crops of 256-px tiles), small batch, K = 2048: teacher / student
-    logits, loss, centre sum and every parameter gradient of one forward/backward against the oracle.
-
-    Loss gate 2.5e-3 here (north_star: 1e-3): with 1-2 tiles the loss is a mean over only 18-36 crop
-    pairs and the bf16 logit noise (measured <= 1 % of max |logit|, gate 2 %) passes through the
-    tau_t = 0.04 teacher softmax un-averaged: tools/parity_sweep.py measured |dloss| between 4e-5 and
-    1.7e-3 over seeds / configs at this size; the B = 8, 100-step curve test holds 1.7e-4."""
+    ViT-B/16 with 2 global + 8 local crops of 256-px tiles) at B = 8, plus the full K = 65536 head: teacher /
+    student logits, loss, centre sum and every parameter gradient of one forward/backward against the oracle,
+    at north_star's gates (loss |d| <= 1e-3, logits 2 %, gradients 5 %, grad-norm 1 %)."""
     from gipvit.engine import DinoEngine
     from oracle import step_oracle as so, vit_oracle as vo
-    K = 2048
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
     orc = so.DinoOracle(arch=arch, img_size=224, out_dim=K, seed=0, n_local=n_local)
     eng = DinoEngine(arch=arch, img_size=224, out_dim=K, batch=B, n_local=n_local, device=dev)
     eng.load_state(orc.p, orc.hp)
@@ -121,9 +118,11 @@ def test_dino_forward_backward_parity_configs(dev, arch, n_local, B):
     for got, ref, nm in ((eng.hb_t.logits, t_out, "teacher"), (eng.hb_s.logits, s_out, "student")):
         err = float((got.cpu() - ref).abs().max())
         assert err <= 2e-2 * float(ref.abs().max()), (nm, err, float(ref.abs().max()))
-    assert abs(float(eng.loss) - float(loss_r)) <= 2.5e-3, (float(eng.loss), float(loss_r))
+    dl = abs(float(eng.loss) - float(loss_r))
+    worst, gn = _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))
+    print(f"[parity {arch} L{n_local} B{B} K{K}] |dloss| {dl:.2e}  worst grad {worst[0]:.2e} ({worst[1]})  grad-norm rel {gn:.2e}")
+    assert dl <= 1e-3, (float(eng.loss), float(loss_r))
     assert _rel(eng.center_sum, bsum[0]) < 1e-2
-    _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))
 
 
 @gpu
@@ -201,35 +200,6 @@ def test_feature_extractor_matches_oracle(dev):
     assert _rel(feats, ref_f) < 2e-2 and _rel(logits, ref_l) < 3e-2, (_rel(feats, ref_f), _rel(logits, ref_l))
 
 
-@pytest.mark.graph_experimental
-def test_dino_graph_replay_matches_eager(dev):
-    """The captured hipGraph step and the eager step follow the same loss trajectory.
-    NOT part of `-m gpu`: on ROCm 7.2 graph replay is not reliably ordered against stream work
-    (DESIGN.md section 7), so the engine's default -- and everything benchmarked -- is eager."""
-    from gipvit.engine import DinoEngine
-    from oracle import step_oracle as so, vit_oracle as vo
-    K, B = 2048, 2
-    orc = so.DinoOracle(arch="vit_tiny", img_size=224, out_dim=K, seed=0)
-    tiles = vo.synth_tiles(B, 256, seed=7).to(dev)
-    losses = []
-    for mode in ("eager", "graph"):
-        # lr 2e-5: the split-K / finalize atomics make summation order run-dependent, and at the
-        # recipe's 5e-4 Adam amplifies that last-bit noise to 5e-2 within four steps on B=2
-        eng = DinoEngine(arch="vit_tiny", img_size=224, out_dim=K, batch=B, lr=2e-5, device=dev)
-        eng.load_state(orc.p, orc.hp)
-        if mode == "graph":
-            eng.capture(tiles)
-            eng.load_state(orc.p, orc.hp)      # capture warm-up ran forward/backward only; reset anyway
-            eng.arena.m.zero_(); eng.arena.v.zero_(); eng.center.zero_(); eng.t = 0
-        ls = []
-        for _ in range(4):
-            l = eng.step_graph(tiles) if mode == "graph" else eng.step(tiles)
-            ls.append(float(l))
-        losses.append(ls)
-    for a, b in zip(*losses):
-        assert abs(a - b) < 2e-3, losses
-
-
 @gpu
 def test_golden_supervised_curve(dev):
     """BASELINE config 1 against the committed fixture (tests/golden/supervised_c1.npz, made by
@@ -257,6 +227,48 @@ def test_golden_supervised_curve(dev):
     err = np.abs(np.array(curve) - gold["curve"])
     print(f"[golden curve] {len(curve)} steps, max |dloss| {err.max():.2e} at step {int(err.argmax())}, final {curve[-1]:.5f} vs {gold['curve'][-1]:.5f}")
     assert float(err.max()) <= 1e-3, (float(err.max()), int(err.argmax()), curve[:5], gold["curve"][:5])
+
+
+@gpu
+def test_golden_dino_curve(dev):
+    """north_star: "loss-vs-step curve matching the CPU reference to 1e-3 over 100 steps" on the DINO step itself.
+    tests/golden/dino_tiny_curve.npz (oracle/make_golden.py): ViT-T, 2x224 + 8x96 crops of eight fresh tiles per step,
+    K = 4096, clip 3.0, and the recipe's schedules -- lr warm-up + cosine, weight decay 0.04 -> 0.4, teacher momentum
+    0.996 -> 1, teacher temperature 0.04 -> 0.07, last layer frozen during the first 25 steps.  Also checks
+    the centre, the teacher (EMA) and the student weights after step 100."""
+    import os
+    import numpy as np
+    from gipvit.engine import DinoEngine
+    from oracle import vit_oracle as vo
+    from oracle.make_golden import dino_curve_schedule
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "dino_tiny_curve.npz"))
+    steps = len(gold["curve"])
+    eng = DinoEngine(arch="vit_tiny", img_size=224, out_dim=4096, batch=8, clip_grad=3.0, device=dev)
+    eng.load_state(vo.init_vit("vit_tiny", 224, 0, seed=0), vo.init_dino_head(192, 4096, seed=1))
+    curve = []
+    for t in range(steps):
+        sch = dino_curve_schedule(t, steps)
+        eng.train_last_layer = sch.pop("train_last_layer")
+        curve.append(eng.step(vo.synth_tiles(8, 256, seed=5000 + t).to(dev), **sch).clone())
+    torch.cuda.synchronize()
+    curve = np.array([float(c) for c in curve])
+    err = np.abs(curve - gold["curve"])
+    print(f"[golden DINO curve] {steps} steps, max |dloss| {err.max():.2e} at step {int(err.argmax())}, final {curve[-1]:.5f} vs {gold['curve'][-1]:.5f}")
+    assert float(err.max()) <= 1e-3, (float(err.max()), int(err.argmax()), curve[:4], gold["curve"][:4])
+    assert _rel(eng.center[:512], torch.from_numpy(gold["center"])) < 1e-2
+    sb, tb = eng.backbone_state_dict(), eng.backbone_state_dict(teacher=True)
+    sh, th = eng.head_state_dict(), eng.head_state_dict(teacher=True)
+    init = torch.from_numpy(gold["init_qkv0"])
+    moved = _rel(torch.from_numpy(gold["s_qkv0"]), init)
+    assert moved > 1e-3, moved                                  # the run did move the weights: the comparison below is not vacuous
+    # the UPDATE (weights minus initial weights) must agree, not just the weights
+    upd_g, upd_r = sb["blocks.0.attn.qkv.weight"][:8, :32].cpu() - init, torch.from_numpy(gold["s_qkv0"]) - init
+    assert _rel(upd_g, upd_r) < 0.2, _rel(upd_g, upd_r)
+    for got, key in ((sb["blocks.0.attn.qkv.weight"], "s_qkv0"), (tb["blocks.0.attn.qkv.weight"], "t_qkv0"), (sb["blocks.11.mlp.fc2.weight"], "s_fc2_11"),
+                     (tb["blocks.11.mlp.fc2.weight"], "t_fc2_11"), (sh["last_layer.weight_v"], "s_last"), (th["last_layer.weight_v"], "t_last"),
+                     (sh["mlp.4.weight"], "s_mlp4")):
+        assert _rel(got[:8, :32], torch.from_numpy(gold[key])) < 2e-3, key
+    assert _rel(sb["pos_embed"][0, :4, :32], torch.from_numpy(gold["s_pos"])) < 2e-3
 
 
 @gpu

@@ -53,6 +53,14 @@ def test_bad_arguments_fail_loudly_without_gpu():
     assert _lib.lib.gv_crop_resize(ctypes.byref(c), None) == -1 and b"multiple of 4" in _lib.lib.gv_last_error()
     rows = (_lib.gv_linear_timing_row * 4)()
     assert _lib.lib.gv_linear_timing_read(rows, 4) == 0             # nothing recorded: zero rows, no GPU touched
+    # epilogue bits outside the documented mask (the tuning lab's ablation switches lived there) are refused
+    d = _lib.gv_linear_args()
+    d.A = d.B = d.C = 256; d.M = d.N = d.K = 128; d.lda = d.ldb = d.ldc = 128
+    for bad in (1 << 20, 1 << 21, 1 << 22, 128):
+        d.epilogue = bad
+        assert _lib.lib.gv_linear(ctypes.byref(d), None) == -4 and b"GV_EPI" in _lib.lib.gv_last_error(), bad
+    e = _lib.gv_adamw_ema_args(); e.p = e.grad = e.m = e.v = 256; e.n = 64; e.mode = 4
+    assert _lib.lib.gv_adamw_ema(ctypes.byref(e), None) == -4
 
 
 def test_arena_layout_and_decay_split():
@@ -166,10 +174,115 @@ def test_transformations_hook_and_tile_files(tmp_path):
             D.write_tile_file(str(tmp_path / s / f"tile_{i}.data"), (a + i).astype(np.uint8))
     (tmp_path / "labels.csv").write_text("slide,label\nslideA,1\nslideB,0\n")
     assert np.array_equal(D.read_tile_file(str(tmp_path / "slideA" / "tile_2.data")), (a + 2).astype(np.uint8))
-    src = D.TileFolder(str(tmp_path), batch=2, transform=None, seed=0)
+    # one epoch = n_slides x n_tiles draws, draw i = a random tile of slide i % n_slides (datasets.py:428-429, 445-450)
+    src = D.TileFolder(str(tmp_path), batch=2, transform=None, seed=0, n_tiles=3)
     batches = list(src)
-    assert len(batches) == 2 and batches[0]["Data"].shape == (2, 256, 256, 3) and batches[0]["Data"].dtype == torch.uint8
+    assert len(src) == 3 and len(batches) == 3 and batches[0]["Data"].shape == (2, 256, 256, 3) and batches[0]["Data"].dtype == torch.uint8
     assert batches[0]["Target"].shape == (2, 1) and batches[0]["Target"].dtype == torch.int64
+    tg = torch.cat([b["Target"] for b in batches]).view(-1)
+    assert int(tg.sum()) == 3                                         # every slide drawn n_tiles times: 3 x label 1, 3 x label 0
+    for b in batches:                                                 # every tile is one of its slide's files, read byte-exactly
+        for t, y in zip(b["Data"], b["Target"].view(-1)):
+            assert any(np.array_equal(t.numpy(), (a + i).astype(np.uint8)) for i in range(3 if y else 2))
+    # ranks get the same number of batches whatever the remainder (5 slides... here 2 x 3 = 6 draws, world 2, B 2 -> 1 batch each)
+    r0, r1 = (D.TileFolder(str(tmp_path), batch=2, rank=r, world=2, seed=0, n_tiles=3) for r in (0, 1))
+    assert len(r0) == len(r1) == 1
+    with pytest.raises(ValueError):
+        D.TileFolder(str(tmp_path), batch=64, seed=0, n_tiles=3)
+
+
+def test_infer_tiles_chunks_and_labels(tmp_path):
+    """Infer_Dataset's contract (datasets.py:634-817): per slide min(num_tiles, available) tiles in chunks of
+    tiles_per_iter, 'Is Last Batch' on the chunk that ends a slide; labels / folds / --target from labels.csv."""
+    import numpy as np
+    from gipvit import data as D
+    a = (np.arange(64 * 64 * 3) % 251).astype(np.uint8).reshape(64, 64, 3)
+    for s, n in (("s0", 5), ("s1", 2), ("s2", 7)):
+        os.makedirs(tmp_path / s)
+        for i in range(n):
+            D.write_tile_file(str(tmp_path / s / f"tile_{i}.data"), (a + i).astype(np.uint8))
+    (tmp_path / "labels.csv").write_text("slide,label,fold,ER\ns0,1,1,Negative\ns1,0,2,Positive\ns2,1,1,Positive\n")
+    inf = D.InferTiles(str(tmp_path), tile_size=64, tiles_per_iter=3, num_tiles=6, seed=0)
+    assert inf.num_tiles == [5, 2, 6] and inf.image_file_names == ["s0", "s1", "s2"] and len(inf) == 2 + 1 + 2
+    got = list(inf)
+    assert [g["Is Last Batch"] for g in got] == [False, True, True, False, True]
+    assert [g["Data"].shape[0] for g in got] == [3, 2, 2, 3, 3] and [int(g["Label"]) for g in got] == [1, 1, 0, 1, 1]
+    assert got[0]["Slide Filename"] == "s0" and sorted(got[0]["Patch Loc"] + got[1]["Patch Loc"]) == [0, 1, 2, 3, 4]
+    for g in got[:2]:
+        for t, i in zip(g["Data"], g["Patch Loc"]):
+            assert np.array_equal(t.numpy(), (a + i).astype(np.uint8))
+    inf.reset_counter(); assert inf.slide_num == -1
+    # --target picks a named label column ('Positive' / 'Negative' strings as in the reference's slide tables)
+    sl = D.scan_slides(str(tmp_path), "ER")
+    assert [s[2] for s in sl] == [0, 1, 1] and [s[3] for s in sl] == ["1", "2", "1"]
+    assert [s[0] for s in D.select_fold(sl, 1, train=True)] == ["s1"] and [s[0] for s in D.select_fold(sl, 1, train=False)] == ["s0", "s2"]
+    syn = D.SyntheticSlides(n_slides=3, tiles_per_slide=5, tile_size=32, tiles_per_iter=2)
+    chunks = list(syn)
+    assert len(chunks) == len(syn) == 9 and sum(c["Is Last Batch"] for c in chunks) == 3 and chunks[2]["Data"].shape == (1, 32, 32, 3)
+
+
+def test_validate_metrics_host_logic():
+    from gipvit.validate import accuracy_topk
+    import numpy as np
+    prob = np.array([[0.9, 0.1], [0.2, 0.8], [0.6, 0.4], [0.3, 0.7]])
+    a1, a5 = accuracy_topk(prob, np.array([0, 1, 1, 1]))
+    assert a1 == 75.0 and a5 == 100.0                                  # top-5 of 2 classes always hits (timm semantics)
+
+
+def test_every_used_flag_is_read_by_the_driver():
+    """CLI honesty: a reference flag marked used=True in cli_spec must be read (``args.<dest>``) by train.py; a flag the
+    driver never looks at must be marked used=False so it lands in the 'accepted, ignored' warning."""
+    sys.path.insert(0, ROOT)
+    import train
+    from gipvit.cli_spec import REFERENCE_FLAGS
+    src = open(os.path.join(ROOT, "train.py")).read()
+    for e in REFERENCE_FLAGS:
+        dest = train.flag_dest(e)
+        reads = len(re.findall(r"args\." + re.escape(dest) + r"\b", src))
+        if e["used"]:
+            assert reads > 0, f"{e['flags']} is marked used but train.py never reads args.{dest}"
+        elif e["flags"][0] != "data":
+            assert reads == 0, f"{e['flags']} is read by train.py but marked used=False"
+    # values the build cannot honour are refused before any GPU work
+    for bad in (["--drop", "0.1"], ["--drop-path", "0.1"], ["--pretrained"], ["--clip-mode", "agc"], ["--in-chans", "1"],
+                ["--input-size", "3", "224", "200"], ["--dino", "--supervised"]):
+        args, _ = train.parse_args(["--model", "vit_tiny"] + bad)
+        with pytest.raises(SystemExit):
+            train.check_supported(args, lambda m: None)
+    args, _ = train.parse_args(["--model", "vit_tiny", "--input-size", "3", "64", "64", "--amp", "--amp-dtype", "bfloat16"])
+    assert train.check_supported(args, lambda m: None) == 64
+    ns = lambda **k: type("A", (), dict(warmup_teacher_temp=0.04, teacher_temp=0.07, **k))
+    assert train.teacher_temp_at(ns(warmup_teacher_temp_epochs=0), 0) == 0.07          # no warm-up: the final temperature from step 0
+    assert train.teacher_temp_at(ns(warmup_teacher_temp_epochs=3), 0) == 0.04 and abs(train.teacher_temp_at(ns(warmup_teacher_temp_epochs=3), 1) - 0.055) < 1e-12
+    assert train.teacher_temp_at(ns(warmup_teacher_temp_epochs=3), 2) == 0.07 and train.teacher_temp_at(ns(warmup_teacher_temp_epochs=3), 9) == 0.07
+
+
+def test_bench_launcher_spawns_ranks_with_torchrun_env(tmp_path):
+    """`python bench.py --gpus N` without WORLD_SIZE is only a launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, rank 0's stdout relayed.  Exercised with a stub child (no GPU)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text("import os, sys, json\n"
+                    "e = {k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}\n"
+                    "open(os.path.join(os.path.dirname(__file__), 'rank%s.json' % e['RANK']), 'w').write(json.dumps([e, sys.argv[1:]]))\n"
+                    "print(json.dumps({'rank': e['RANK'], 'rccl_ranks': int(e['WORLD_SIZE'])}))\n"
+                    "sys.exit(3 if e['RANK'] == '2' and '--fail' in sys.argv else 0)\n")
+    import json
+    rc, out = bench.launch_children(3, ["--gpus", "3", "--steps", "2"], child=[sys.executable, str(stub)], timeout=60)
+    assert rc == 0 and json.loads(out) == {"rank": "0", "rccl_ranks": 3}
+    envs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(3)]
+    assert [e[0]["RANK"] for e in envs] == ["0", "1", "2"] and all(e[0]["WORLD_SIZE"] == "3" and e[0]["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert len({e[0]["MASTER_PORT"] for e in envs}) == 1 and envs[1][1] == ["--gpus", "3", "--steps", "2"]
+    rc, _ = bench.launch_children(3, ["--fail"], child=[sys.executable, str(stub)], timeout=60)
+    assert rc == 3                                                       # a failing rank fails the launch
+    # end to end through main(): bare `--gpus 2` in a process without WORLD_SIZE goes to the launcher, not to the GPU
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.argv = ['bench.py', '--gpus', '2', '--steps', '1']\n"
+                        "import bench\n"
+                        f"bench.launch_children = lambda n, argv, **k: (0, 'LAUNCHED %d %s\\n' % (n, ' '.join(argv)))\n"
+                        "bench.main()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "LAUNCHED 2 --gpus 2 --steps 1" in r.stdout, (r.stdout, r.stderr)
 
 
 def test_lr_schedule_and_checkpoint_saver(tmp_path):

@@ -191,3 +191,40 @@ def test_multicrop_sampler_boxes():
     from oracle import augment_oracle as ao        # same algorithm, restated
     y0, x0, h, w = ao.sample_box(np.random.default_rng(1), 256, 256, (0.05, 0.4))
     assert 0 <= y0 and y0 + h <= 256 and 0 <= x0 and x0 + w <= 256
+
+
+def test_weight_decay_sets_agree_name_by_name():
+    """Oracle (AdamW restatement) and engine (arena layout) must decay exactly the same parameters -- timm's
+    create_optimizer_v2 filter: 1-D tensors, *.bias, pos_embed, cls_token are excluded -- for the
+    supervised model (bare names) and for the DINO student ('backbone.' / 'head.' prefixes)."""
+    from gipvit import engine as E
+    sup = so.SupervisedOracle(arch="vit_tiny", img_size=64, num_classes=2)
+    specs = E.vit_param_specs("vit_tiny", 64, 2)
+    assert list(specs) == list(sup.p)
+    for n, t in sup.p.items():
+        assert vo.no_weight_decay(n, t) == E.no_weight_decay(n, specs[n]), n
+    d = so.DinoOracle(arch="vit_tiny", img_size=64, out_dim=256)
+    from collections import OrderedDict
+    specs = OrderedDict(("backbone." + k, v) for k, v in E.vit_param_specs("vit_tiny", 64, 0).items())
+    specs.update(("head." + k, v) for k, v in E.dino_head_specs(192, 256).items())
+    assert set(specs) == set(d.all)
+    nd_o = {n for n, t in d.all.items() if vo.no_weight_decay(n, t)}
+    nd_e = {n for n, sh in specs.items() if E.no_weight_decay(n, sh)}
+    assert nd_o == nd_e, (nd_o ^ nd_e)
+    assert {"backbone.pos_embed", "backbone.cls_token", "backbone.norm.weight", "head.mlp.0.bias", "head.last_layer.weight_g"} <= nd_o
+    assert "backbone.patch_embed.proj.weight" not in nd_o and "head.last_layer.weight_v" not in nd_o
+
+
+def test_golden_dino_curve_fixture_reproduces():
+    """First steps of the 100-step DINO curve fixture (schedules, frozen last layer) re-run on the oracle."""
+    from oracle.make_golden import dino_curve_schedule
+    gold = np.load(os.path.join(GOLD, "dino_tiny_curve.npz"))
+    assert len(gold["curve"]) == 100
+    orc = so.DinoOracle(arch="vit_tiny", img_size=224, out_dim=4096, seed=0, clip_grad=3.0)
+    for t in range(2):
+        r = orc.step(vo.synth_tiles(8, 256, seed=5000 + t), **dino_curve_schedule(t, 100))
+        assert abs(r["loss"] - gold["curve"][t]) < 2e-4 and abs(r["grad_norm"] - gold["grad_norm"][t]) < 1e-3 * gold["grad_norm"][t]
+    s0, s99 = dino_curve_schedule(0), dino_curve_schedule(99)
+    assert s0["lr"] == 1e-6 and not s0["train_last_layer"] and s0["teacher_temp"] == 0.04 and abs(s0["wd"] - 0.04) < 1e-12 and abs(s0["momentum_teacher"] - 0.996) < 1e-12
+    assert s99["train_last_layer"] and s99["teacher_temp"] == 0.07 and abs(s99["wd"] - 0.4) < 1e-12 and abs(s99["momentum_teacher"] - 1.0) < 1e-12
+    assert abs(dino_curve_schedule(25)["lr"] - 5e-4 * 8 / 256) < 2e-6

@@ -1,7 +1,7 @@
 // GEMM lab: times gemm_core.h under several tile / wave / ring geometries and k-loop schedules on the hot
 // path's shapes, all in one process (interleaved rounds), and byte-compares every configuration's output with
 // the first one run on the same shape.  Not part of the library.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/gemm_lab.hip -o tools/gemm_lab   [-DGV_GEMM_STAMPS]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGV_GEMM_LAB -I include tools/gemm_lab.hip -o tools/gemm_lab   [-DGV_GEMM_STAMPS]
 //   LAB_T=44160 LAB_FULL_ONLY=1 [LAB_PM=1] [LAB_CFGS=0,4] ./tools/gemm_lab [cfg [shape]]
 // LAB_T: token rows; LAB_FULL_ONLY: skip the ablation variants; LAB_PM: persistent grid multiplier; LAB_CFGS: list.
 #include "../gipmed-project-self-supervised-vit_amd/csrc/gemm_core.h"

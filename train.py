@@ -8,10 +8,13 @@ ViT path only.
 
 What it keeps from the reference (file:line = /root/reference/train.py):
   * the whole CLI surface (83-393, table in gipvit/cli_spec.py) + ``-c FILE`` YAML defaults (396-410);
-  * step order (1044-1078): forward -> softmax -> LabelSmoothingCE -> backward -> clip -> optimizer;
+  * step order (1044-1078): forward -> softmax -> LabelSmoothingCE -> backward -> clip -> optimizer -> model EMA;
   * lr = lr_base * global_batch / 256 (569-581), cosine/step schedule with warm-up (881-887);
   * the ``Train: ep [i/n] Loss .. Time .. rate/s LR .. Data ..`` log line (1096-1111);
-  * output folder layout, ``args.yaml``, ``summary.csv``, checkpoint file names (854-879, 958-973);
+  * the epoch loop (905-977): train -> slide-level ``validate`` (933, 1146-1345) -> EMA validate (943-955) ->
+    summary.csv -> checkpoint on ``--eval-metric`` (970-973); ``--extract_features`` skips training and writes
+    ``./TCGA_500/<slide>_features.pt`` (906, 1281-1282);
+  * output folder layout, ``args.yaml``, checkpoint file names / keys incl. ``state_dict_ema`` (854-879);
   * batch dict keys 'Data' / 'Target' (1027-1028) and the ``define_transformations`` hook.
 Deliberate deviations: the device is threaded through (the reference is
 hard-wired to cuda and unrunnable on CPU -- here a GPU is REQUIRED, there is no CPU fallback);
@@ -19,6 +22,8 @@ W&B is optional; the LR is stepped every update with --sched-on-updates (the ref
 inside the log-interval block, 1087/1130-1137); AUC is computed at log time from device-side
 probabilities instead of a per-step D2H sync (1054); tiles are sharded over ranks.
 ``--dino`` adds the DINO multi-crop SSL step the north-star names (absent from the reference).
+Every reference flag marked ``used`` in gipvit/cli_spec.py is read below (tests/test_host.py enforces it); a value
+this build cannot honour is REJECTED, never silently ignored.
 """
 from __future__ import annotations
 
@@ -46,6 +51,14 @@ from gipvit.cli_spec import REFERENCE_FLAGS  # noqa: E402
 
 _logger = logging.getLogger("train")
 _TYPES = {"int": int, "float": float, "str": str}
+
+
+def flag_dest(e) -> str:
+    """argparse's dest for a cli_spec entry: explicit ``dest``, else the first long option."""
+    if e.get("dest"):
+        return e["dest"]
+    longs = [f for f in e["flags"] if f.startswith("--")]
+    return (longs[0] if longs else e["flags"][0]).lstrip("-").replace("-", "_")
 
 
 def build_parser():
@@ -76,7 +89,9 @@ def build_parser():
     g.add_argument("--freeze-last-layer", type=int, default=1, help="epochs during which the head's last layer is not updated")
     g.add_argument("--tile-size", type=int, default=256)
     g.add_argument("--batches-per-epoch", type=int, default=100, help="synthetic source only")
-    g.add_argument("--graph", action="store_true", help="EXPERIMENTAL: capture the DINO step in a hipGraph (DESIGN.md section 7)")
+    g.add_argument("--synthetic-slides", type=int, default=4, help="synthetic source only: slides of the inference set")
+    g.add_argument("--no-validate", action="store_true", help="skip the per-epoch slide-level validation")
+    g.add_argument("--features-dir", default="./TCGA_500", help="where --extract_features writes <slide>_features.pt (train.py:1282)")
     g.add_argument("--device", default="cuda", help="must be a GPU: the hot path has no CPU fallback")
     return cfg, p
 
@@ -91,6 +106,40 @@ def parse_args(argv=None):
     return args, yaml.safe_dump(vars(args), default_flow_style=False)
 
 
+def check_supported(args, log=_logger.warning):
+    """Reference flags whose value this build cannot honour are rejected loudly; the ones it maps onto its own
+    arithmetic are explained once.  Returns the resolved image size (or None)."""
+    if args.drop:
+        raise SystemExit(f"--drop {args.drop}: dropout is not built into the fused epilogues (reference train.py:283-284, vit.pyc@L98-104); "
+                         "only the reference default 0.0 is supported")
+    if args.drop_path:
+        raise SystemExit(f"--drop-path {args.drop_path}: stochastic depth is not built (reference train.py:287-288, vit.pyc@L66-74); "
+                         "only the reference default (None / 0) is supported")
+    if args.pretrained and not args.initial_checkpoint:
+        raise SystemExit("--pretrained downloads weights by URL (reference train.py:482-485): there is no network here -- "
+                         "pass the file with --initial-checkpoint instead")
+    if args.clip_mode != "norm":
+        raise SystemExit(f"--clip-mode {args.clip_mode}: only global-norm clipping ('norm', the reference default, train.py:1072-1077) is fused "
+                         "into the optimizer kernel")
+    if args.in_chans not in (None, 3):
+        raise SystemExit(f"--in-chans {args.in_chans}: the patch-embedding kernel reads 3-channel NHWC uint8 tiles")
+    img = None
+    if args.input_size:
+        c, h, w = args.input_size
+        if c != 3 or h != w or h % 16:
+            raise SystemExit(f"--input-size {args.input_size}: need 3 x S x S with S a multiple of 16")
+        img = h
+    if args.amp and args.amp_dtype not in ("bfloat16", "bf16"):
+        log(f"--amp --amp-dtype {args.amp_dtype}: fp16 autocast + loss scaling (train.py:452-465, 585-602) is not built; this build's "
+            "GEMMs always take bf16 operands with f32 accumulation and f32 master weights (the --amp-dtype bfloat16 arithmetic)")
+    elif not args.amp:
+        log("no --amp: the reference would compute in fp32 (train.py:452-465); this build's GEMMs take bf16 operands with f32 "
+            "accumulation, f32 residual stream and f32 master weights (the --amp --amp-dtype bfloat16 arithmetic)")
+    if args.supervised and args.dino:
+        raise SystemExit("--supervised (fine-tune with labels, train.py:715-717) and --dino (self-supervised) exclude each other")
+    return img
+
+
 class Meter:
     def __init__(self):
         self.val = self.sum = self.n = 0.0
@@ -103,6 +152,18 @@ class Meter:
         return self.sum / max(self.n, 1)
 
 
+def teacher_temp_at(args, epoch: int) -> float:
+    """DINO's teacher-temperature schedule: linear warm-up from --warmup-teacher-temp to --teacher-temp over the first
+    --warmup-teacher-temp-epochs epochs (np.linspace over those epochs), --teacher-temp afterwards -- and from step 0
+    when there is no warm-up."""
+    n = args.warmup_teacher_temp_epochs
+    if n <= 0 or epoch >= n:
+        return args.teacher_temp
+    if n == 1:
+        return args.warmup_teacher_temp
+    return args.warmup_teacher_temp + (args.teacher_temp - args.warmup_teacher_temp) * epoch / (n - 1)
+
+
 def main(argv=None):
     args, args_text = parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(message)s")
@@ -110,6 +171,8 @@ def main(argv=None):
         raise SystemExit("train.py: an MI355X is required (device=%s, cuda available=%s); the HIP hot path has no CPU fallback"
                          % (args.device, torch.cuda.is_available()))
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", args.local_rank))
+    primary = rank == 0
+    img_from_input_size = check_supported(args, _logger.warning if primary else (lambda m: None))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     reducer = None
@@ -118,17 +181,24 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=dev)         # RCCL
         from gipvit.dist import RcclReducer
         reducer = RcclReducer()
-    primary = rank == 0
     torch.manual_seed(args.seed + rank)                        # utils.random_seed(seed, rank), train.py:467
 
     ignored = [e["flags"][-1] for e in REFERENCE_FLAGS if not e["used"] and e["flags"][-1].startswith("-")
-               and getattr(args, (e.get("dest") or e["flags"][-1].lstrip("-")).replace("-", "_"), None) not in (e.get("default"), None, False)]
+               and getattr(args, flag_dest(e), None) not in (e.get("default"), None, False)]
     if ignored and primary:
         _logger.warning("flags accepted for CLI compatibility but outside this build's hot path: %s", " ".join(ignored))
+    run = None
+    if args.log_wandb and primary:                             # train.py:447-450 (optional here; credentials from the environment only)
+        try:
+            import wandb
+            run = wandb.init(project=args.experiment or "gipvit", group=args.group or None, config=vars(args))
+        except Exception as ex:                                # not installed / offline
+            _logger.warning("--log-wandb: wandb unavailable (%s); metrics go to the log and summary.csv only", ex)
 
     from gipvit import models as M, sched as S, data as D, transformations as T
-    from gipvit.engine import DinoEngine, SupervisedEngine
+    from gipvit.engine import DinoEngine, SupervisedEngine, FeatureExtractor, Weights
     from gipvit.checkpoint import CheckpointSaver, load_checkpoint_file
+    from gipvit.validate import validate
     arch = M.resolve_arch(args.model)
     B = args.batch_size
     mean = tuple(args.mean) if args.mean else T.MEAN["Ron"]
@@ -141,21 +211,39 @@ def main(argv=None):
     betas = tuple(args.opt_betas) if args.opt_betas else (0.9, 0.999)
     eps = args.opt_eps if args.opt_eps is not None else 1e-8
 
-    # ---- data (batch dict contract of the reference: 'Data', 'Target')
-    transform = T.define_transformations(args.transform_type if args.dataset not in ("", "synthetic") else "none", True, tile,
-                                         args.c_param, "Ron")
-    if args.dataset in ("", "synthetic"):
+    # ---- data (batch dict contract of the reference: 'Data', 'Target'; inference: Infer_Dataset's dict)
+    synthetic = args.dataset in ("", "synthetic")
+    transform = T.define_transformations(args.transform_type if not synthetic else "none", True, tile, args.c_param, "Ron")
+    inf_loader = None
+    if synthetic:
         source = D.SyntheticTiles(B, tile, args.batches_per_epoch, args.num_classes or 2, seed=args.seed + rank)
+        if not args.no_validate and (not args.dino or args.extract_features):
+            inf_loader = D.SyntheticSlides(args.synthetic_slides, min(args.num_tiles, 2 * B), tile, args.tiles_per_iter, seed=args.seed + 99)
     elif args.dataset.startswith("tiles:") or args.data_dir:
         root = args.dataset[6:] if args.dataset.startswith("tiles:") else args.data_dir
-        source = D.TileFolder(root, B, transform, rank, world, args.seed, tile)
+        slides = D.scan_slides(root, args.target)
+        train_slides, eval_slides = D.select_fold(slides, args.test_fold, True), D.select_fold(slides, args.test_fold, False)
+        if args.supervised:
+            # train.py:715-717: --supervised re-splits the TEST-fold set 80 / 20 into train / eval
+            import numpy as np
+            perm = np.random.default_rng(args.seed).permutation(len(eval_slides))
+            k = max(1, int(len(eval_slides) * 0.8))
+            train_slides, eval_slides = [eval_slides[i] for i in perm[:k]], [eval_slides[i] for i in perm[k:]] or eval_slides
+        source = D.TileFolder(root, B, transform, rank, world, args.seed, tile, n_tiles=args.n_patches_train, workers=args.workers,
+                              slides=train_slides)
+        if not args.no_validate and (not args.dino or args.extract_features):
+            inf_loader = D.InferTiles(root, tile, args.tiles_per_iter, args.num_tiles, seed=args.seed, dataset_name=args.dataset,
+                                      workers=args.workers, slides=eval_slides)
     else:
         raise SystemExit(f"--dataset {args.dataset}: whole-slide datasets need openslide and are outside this build "
                          "(SURVEY section 2 #15); use 'synthetic' or 'tiles:<dir>' with pre-extracted tile_<i>.data files")
     updates_per_epoch = len(source)
 
     # ---- model + engine
+    ema_decay = args.model_ema_decay if args.model_ema else None                 # train.py:615-622
     if args.dino:
+        if args.model_ema and primary:
+            _logger.warning("--model-ema with --dino: the DINO teacher IS the EMA model (momentum schedule --momentum-teacher); flag has no further effect")
         img = args.global_crop_size
         eng = DinoEngine(arch=arch, img_size=img, out_dim=args.out_dim, batch=B, tile=tile, n_local=args.local_crops_number,
                          gsize=args.global_crop_size, lsize=args.local_crop_size, lr=lr, weight_decay=args.weight_decay, betas=betas, eps=eps,
@@ -164,55 +252,91 @@ def main(argv=None):
         bb = (M.load_encoder_checkpoint(args.initial_checkpoint, arch, img) if args.initial_checkpoint
               else M.init_vit_state(arch, img, 0, seed=args.seed))
         eng.load_state(bb, M.init_dino_head_state(eng.D, args.out_dim, seed=args.seed + 1))
+        nc = 0
     else:
-        img = args.img_size or tile          # the reference patches timm's default cfg to 256 (train_instruct.txt:9-13)
+        img = args.img_size or img_from_input_size or tile   # the reference patches timm's default cfg to 256 (train_instruct.txt:9-13)
         nc = args.num_classes or 2
         eng = SupervisedEngine(arch=arch, img_size=img, num_classes=nc, batch=B, lr=lr, weight_decay=args.weight_decay, betas=betas, eps=eps,
                                smoothing=args.smoothing, clip_grad=args.clip_grad or 0.0, mean=mean, std=std, device=dev, reducer=reducer,
                                opt=opt if opt in ("adam", "adamw", "sgd") else "adamw", momentum=args.momentum,
-                               train_backbone=not args.no_grad)
+                               train_backbone=not args.no_grad, model_ema_decay=ema_decay)
         st = (M.load_encoder_checkpoint(args.initial_checkpoint, arch, img, nc) if args.initial_checkpoint
               else M.init_vit_state(arch, img, nc, seed=args.seed))
         eng.load_state(st)
     start_epoch = args.start_epoch or 0
     if args.resume:
         ck = load_checkpoint_file(args.resume)
-        sd = {k[7:] if k.startswith("module.") else k: v for k, v in ck["state_dict"].items()}
+        strip = lambda d: {k[7:] if k.startswith("module.") else k: v for k, v in d.items()}
+        sd = strip(ck["state_dict"])
+        sub = lambda d, pre: {k[len(pre):]: v for k, v in d.items() if k.startswith(pre)}
         if args.dino:
-            eng.load_state({k[9:]: v for k, v in sd.items() if k.startswith("backbone.")}, {k[5:]: v for k, v in sd.items() if k.startswith("head.")})
+            eng.load_state(sub(sd, "backbone."), sub(sd, "head."))
+            if "state_dict_ema" in ck:        # the teacher + centre: without them the run would restart the EMA from the student
+                te = strip(ck["state_dict_ema"])
+                eng.load_teacher_state(sub(te, "backbone."), sub(te, "head."), ck.get("dino_center"))
+            elif primary:
+                _logger.warning("--resume: %s holds no teacher ('state_dict_ema'); the teacher restarts as a copy of the student", args.resume)
         else:
-            eng.load_state(sd)
+            eng.load_state(sd, strip(ck["state_dict_ema"]) if (ema_decay is not None and "state_dict_ema" in ck) else None)
         if "optimizer" in ck and not args.no_resume_opt:
             eng.arena.m.copy_(ck["optimizer"]["exp_avg"]); eng.arena.v.copy_(ck["optimizer"]["exp_avg_sq"]); eng.t = int(ck["optimizer"]["step"])
         start_epoch = args.start_epoch if args.start_epoch is not None else ck.get("epoch", -1) + 1
+    if hasattr(source, "epoch"):
+        source.epoch = start_epoch                 # the synthetic source seeds every epoch: a resumed run sees epoch k's tiles
     if primary:
         n_params = sum(int(torch.tensor(s).prod()) for s in eng.arena.specs.values())
         _logger.info(f"Model {args.model} ({arch}) created, param count:{n_params}")
 
+    # ---- forward-only runners for validation / feature extraction: they evaluate the engine's LIVE weights
+    eval_B = min(256, max(B, 32))
+    runner = runner_ema = None
+    if inf_loader is not None:
+        if args.dino:       # features come from the teacher backbone (the model DINO users evaluate)
+            runner = FeatureExtractor(arch, tile, eval_B, 0, mean, std, dev, weights=Weights(eng.arena, "backbone.", teacher=True))
+            if tile != img:
+                raise SystemExit(f"--extract_features with --dino: tile size {tile} must equal the teacher's image size {img}")
+        else:
+            runner = FeatureExtractor(arch, img, eval_B, nc, mean, std, dev, weights=eng.W)
+            if ema_decay is not None:
+                runner_ema = FeatureExtractor(arch, img, eval_B, nc, mean, std, dev, weights=eng.Wema)
+
     # ---- output dir, args.yaml, saver (train.py:854-879)
+    eval_metric = args.eval_metric                              # train.py:849
+    decreasing = eval_metric == "loss"                          # train.py:866
     saver = output_dir = None
     if primary:
         exp = args.experiment or "-".join([time.strftime("%Y%m%d-%H%M%S"), args.model.replace("/", "_"), str(img)])
         output_dir = os.path.join(args.output or "./output/train", exp, args.subexperiment or "")
         os.makedirs(output_dir, exist_ok=True)
-        saver = CheckpointSaver(output_dir, args.model, vars(args), decreasing=True, max_history=args.checkpoint_hist)
+        saver = CheckpointSaver(output_dir, args.model, vars(args), decreasing=decreasing or inf_loader is None or args.dino,
+                                max_history=args.checkpoint_hist)
         with open(os.path.join(output_dir, "args.yaml"), "w") as f:
             f.write(args_text)
     schedule = S.LrSchedule(lr, args.sched, args.epochs, args.warmup_epochs, args.warmup_lr, args.min_lr, updates_per_epoch,
                             args.decay_epochs, args.decay_rate, on_updates=args.sched_on_updates or args.dino)
     total_updates = args.epochs * updates_per_epoch
-    use_graph = args.dino and args.graph
-    feats_out = []
     sampler = None
     if args.dino and args.random_crops:       # DINO recipe: random-resized crops + flips, cut on the device
         from gipvit.multicrop import MultiCropSampler
         sampler = MultiCropSampler(B, tile, 2, args.local_crops_number, tuple(args.global_crops_scale), tuple(args.local_crops_scale),
                                    seed=args.seed + rank)
 
+    def extra_state():
+        ex = {}
+        if args.dino:       # teacher (the EMA model) + centre: a DINO run cannot be resumed (or evaluated) without them
+            ex["state_dict_ema"] = eng.arena.state_dict(eng.arena.t)
+            ex["dino_center"] = eng.center.detach().cpu()
+        elif ema_decay is not None:
+            ex["state_dict_ema"] = eng.state_dict(ema=True)     # timm CheckpointSaver key
+        return ex
+
     # the step's critical path runs on a high-priority stream; the engine's side stream (teacher forward,
     # weight-gradient GEMMs) fills the CU slots it leaves
     torch.cuda.synchronize()
     torch.cuda.set_stream(torch.cuda.Stream(dev, priority=-1))
+    # tiles reach HBM one batch ahead of the step: pinned staging + a copy stream (replaces pin_memory workers, train.py:732)
+    loader = D.DevicePrefetcher(source, dev, (B, tile, tile, 3))
+    cur_lr = lr
     # ---- epoch loop (train.py:905-977) / step loop (988-1143)
     for epoch in range(start_epoch, args.epochs):
         batch_time, data_time, losses = Meter(), Meter(), Meter()
@@ -221,32 +345,19 @@ def main(argv=None):
         last_idx = updates_per_epoch - 1
         if args.dino:
             eng.train_last_layer = epoch >= args.freeze_last_layer
-            if use_graph and eng.graph is not None and (epoch == args.freeze_last_layer):
-                eng.graph = None                      # the captured step changes when the last layer thaws
-        for batch_idx, mb in enumerate(source):
-            data = mb["Data"].to(dev, non_blocking=True)
-            target = mb["Target"].to(dev, non_blocking=True)
+        for batch_idx, mb in (enumerate(loader) if not args.extract_features else ()):      # train.py:906
+            data, target = mb["Data"], mb["Target"]
             data_time.update(time.time() - end)
             cur_lr = schedule.at(epoch, batch_idx)
-            if args.extract_features and not args.dino:
-                logits, feats = eng.forward(data)
-                feats_out.append(feats.float().cpu())
-                loss_t = eng.loss
-            elif args.dino:
+            if args.dino:
                 it = epoch * updates_per_epoch + batch_idx
                 sch = dict(lr=cur_lr, wd=S.cosine_between(args.weight_decay, args.weight_decay_end, it, total_updates),
                            momentum_teacher=S.cosine_between(args.momentum_teacher, 1.0, it, total_updates),
-                           teacher_temp=(args.warmup_teacher_temp + (args.teacher_temp - args.warmup_teacher_temp)
-                                         * min(1.0, epoch / max(1, args.warmup_teacher_temp_epochs))))
-                if use_graph:
-                    if eng.graph is None:
-                        eng.capture(data)
-                    loss_t = eng.step_graph(data, **sch)
-                else:
-                    loss_t = eng.step(data, boxes=sampler.sample(dev) if sampler is not None else None, **sch)
+                           teacher_temp=teacher_temp_at(args, epoch))
+                loss_t = eng.step(data, boxes=sampler.sample(dev) if sampler is not None else None, **sch)
             else:
                 loss_t = eng.step(data, target, lr=cur_lr)
-                probs.append(eng.prob[:, 1].clone() if eng.C > 1 else eng.prob[:, 0].clone()); targets.append(target.view(-1))
+                probs.append(eng.prob[:, 1].clone() if eng.C > 1 else eng.prob[:, 0].clone()); targets.append(target.view(-1).clone())
             torch.cuda.synchronize()                  # train.py:1083
             batch_time.update(time.time() - end)
             if batch_idx == last_idx or batch_idx % args.log_interval == 0:
@@ -263,18 +374,30 @@ def main(argv=None):
                                      batch_time.val, B * world / batch_time.val, batch_time.avg, B * world / batch_time.avg, cur_lr,
                                      data_time.val, data_time.avg))
                 if saver is not None and args.recovery_interval and (batch_idx + 1) % args.recovery_interval == 0:
-                    saver.save_recovery(epoch, batch_idx, eng.arena.state_dict())
+                    saver.save_recovery(epoch, batch_idx, eng.arena.state_dict(), extra=extra_state())
             end = time.time()
-        # ---- end of epoch: metrics, summary.csv, checkpoint (train.py:958-973)
-        metrics = OrderedDict(loss=losses.avg)
+        # ---- end of epoch: train metrics, slide-level validation (train.py:932-955), summary.csv, checkpoint (958-973)
+        train_metrics = OrderedDict(loss=losses.avg)
         if probs:
             try:
                 from sklearn.metrics import roc_auc_score
-                metrics["auc"] = float(roc_auc_score(torch.cat(targets).cpu().numpy(), torch.cat(probs).float().cpu().numpy()))
+                train_metrics["auc"] = float(roc_auc_score(torch.cat(targets).cpu().numpy(), torch.cat(probs).float().cpu().numpy()))
             except Exception:                       # single-class epoch etc. (the reference would raise, train.py:1054)
-                metrics["auc"] = float("nan")
+                train_metrics["auc"] = float("nan")
+        eval_metrics = OrderedDict()
+        if runner is not None:
+            eval_metrics = validate(runner, inf_loader, extract_features=bool(args.extract_features), smoothing=args.smoothing,
+                                    log_interval=args.log_interval, out_dir=args.features_dir, primary=primary)
+            if runner_ema is not None and not args.extract_features:       # train.py:943-955: the EMA model's metrics win
+                eval_metrics = validate(runner_ema, inf_loader, smoothing=args.smoothing, log_interval=args.log_interval, primary=primary,
+                                        log_suffix=" (EMA)")
+        if args.extract_features:
+            if primary:
+                _logger.info(f"*** features of {int(eval_metrics.get('slides', 0))} slides written to {args.features_dir}")
+            break
         if primary:
-            row = OrderedDict(epoch=epoch, **{"train_" + k: v for k, v in metrics.items()}, lr=cur_lr)
+            row = OrderedDict(epoch=epoch, **{"train_" + k: v for k, v in train_metrics.items()}, **{"eval_" + k: v for k, v in eval_metrics.items()},
+                              lr=cur_lr)
             fn = os.path.join(output_dir, "summary.csv")
             new = not os.path.exists(fn)
             with open(fn, "a") as f:
@@ -282,12 +405,18 @@ def main(argv=None):
                 if new:
                     w.writeheader()
                 w.writerow(row)
+            if run is not None:
+                run.log(dict(row))
             optim = {"exp_avg": eng.arena.m, "exp_avg_sq": eng.arena.v, "step": eng.t}
-            best, best_ep = saver.save_checkpoint(epoch, eng.arena.state_dict(), optim, metric=metrics["loss"])
-            _logger.info(f"*** epoch {epoch}: " + "  ".join(f"{k} {v:.4f}" for k, v in metrics.items()) + f"  (best loss {best:.4f} @ {best_ep})")
-    if args.extract_features and primary and feats_out:
-        os.makedirs("./TCGA_500", exist_ok=True)      # train.py:1281-1282 writes <slide>_features.pt here
-        torch.save(torch.cat(feats_out), os.path.join("./TCGA_500", "synthetic_features.pt"))
+            if eval_metrics:
+                if eval_metric not in eval_metrics:
+                    raise SystemExit(f"--eval-metric {eval_metric}: validate() reports {list(eval_metrics)}")
+                save_metric, name = eval_metrics[eval_metric], "eval " + eval_metric          # train.py:970-973
+            else:
+                save_metric, name = train_metrics["loss"], "train loss"
+            best, best_ep = saver.save_checkpoint(epoch, eng.arena.state_dict(), optim, metric=save_metric, extra=extra_state())
+            _logger.info(f"*** epoch {epoch}: " + "  ".join(f"{k} {v:.4f}" for k, v in list(train_metrics.items()) + [("eval_" + k, v) for k, v in eval_metrics.items()])
+                         + f"  (best {name} {best:.4f} @ {best_ep})")
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0
