@@ -227,4 +227,7 @@ def test_golden_dino_curve_fixture_reproduces():
     s0, s99 = dino_curve_schedule(0), dino_curve_schedule(99)
     assert s0["lr"] == 1e-6 and not s0["train_last_layer"] and s0["teacher_temp"] == 0.04 and abs(s0["wd"] - 0.04) < 1e-12 and abs(s0["momentum_teacher"] - 0.996) < 1e-12
     assert s99["train_last_layer"] and s99["teacher_temp"] == 0.07 and abs(s99["wd"] - 0.4) < 1e-12 and abs(s99["momentum_teacher"] - 1.0) < 1e-12
-    assert abs(dino_curve_schedule(25)["lr"] - 5e-4 * 8 / 256) < 2e-6
+    import math
+    peak = 5e-4 * 8 / 256
+    assert abs(dino_curve_schedule(24)["lr"] - (1e-6 + (peak - 1e-6) * 24 / 25)) < 1e-12                     # end of the linear warm-up
+    assert abs(dino_curve_schedule(25)["lr"] - (1e-6 + 0.5 * (peak - 1e-6) * (1 + math.cos(math.pi / 4)))) < 1e-12   # timm cosine: t / epochs
