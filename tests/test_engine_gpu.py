@@ -82,12 +82,16 @@ def test_dino_step_parity(dev, n_local):
     assert abs(float(eng.loss) - float(loss_r)) <= 1e-3, (float(eng.loss), float(loss_r))
     assert _rel(eng.center_sum, bsum[0]) < 1e-2
     worst, gn = _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))
-    # then full steps (optimizer + EMA + center) stay on the oracle's trajectory
+    # then full steps (optimizer + EMA + center) stay on the oracle's trajectory.  lr 5e-5 here: Adam's first updates are
+    # lr * sign(g) for EVERY weight, so each near-zero gradient component whose sign bf16 noise flips moves a weight by
+    # 2 lr -- at the 5e-4 the oracle was built with (128 x the recipe's 5e-4 * B / 256 for two tiles) that alone measured
+    # |dloss| 8.4e-3 by step 2 (gpurun_out/r2_t1.log); the effect is linear in lr.  The recipe's schedules are held to 1e-3
+    # over 100 steps by test_golden_dino_curve.
     eng.t = 0
     for i in range(3):
-        r = orc.step(tiles)
-        l = eng.step(tiles.to(dev))
-        assert abs(float(l) - r["loss"]) <= 5e-3, (i, float(l), r["loss"])
+        r = orc.step(tiles, lr=5e-5)
+        l = eng.step(tiles.to(dev), lr=5e-5)
+        assert abs(float(l) - r["loss"]) <= 2e-3, (i, float(l), r["loss"])
     torch.cuda.synchronize()
     assert _rel(eng.center, orc.center[0]) < 1e-2
     sd, td = eng.backbone_state_dict(), eng.backbone_state_dict(teacher=True)
