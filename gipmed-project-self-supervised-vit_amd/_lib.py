@@ -42,6 +42,13 @@ gv_linear_args = _struct("gv_linear_args", [
     ("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldb", i64), ("ldc", i64),
     ("trans_a", i32), ("trans_b", i32), ("c_is_f32", i32), ("epilogue", i32), ("bias", vp),
     ("resid", vp), ("ldr", i64), ("aux_in", vp), ("ld_aux", i64), ("aux_out", vp), ("pos", vp), ("P", i32), ("alpha", f32), ("colsum_a", vp), ("workspace", vp), ("workspace_bytes", i64)])
+gv_linear_ln_fwd_args = _struct("gv_linear_ln_fwd_args", [
+    ("A", vp), ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldw", i64), ("bias", vp), ("resid", vp), ("ldr", i64),
+    ("out", vp), ("ldo", i64), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp), ("mean", vp), ("rstd", vp)])
+gv_linear_ln_bwd_args = _struct("gv_linear_ln_bwd_args", [
+    ("A", vp), ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldw", i64), ("x", vp), ("ldx", i64),
+    ("mean", vp), ("rstd", vp), ("gamma", vp), ("g", vp), ("ldg", i64), ("gb", vp), ("ldgb", i64), ("partials", vp),
+    ("partial_blocks", i32), ("g_init", i32)])
 gv_attention_fwd_args = _struct("gv_attention_fwd_args", [
     ("qkv", vp), ("o", vp), ("lse", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32)])
 gv_attention_bwd_args = _struct("gv_attention_bwd_args", [
@@ -77,6 +84,7 @@ gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
 ENTRY_POINTS = {
     "gv_patchify": gv_patchify_args, "gv_crop_resize": gv_crop_resize_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
     "gv_colsum_finalize": gv_colsum_finalize_args, "gv_ln_finalize": gv_ln_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
+    "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args,
     "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_cls_rows": gv_cls_rows_args,
     "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,
@@ -84,12 +92,12 @@ ENTRY_POINTS = {
     "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_store_f32": gv_store_f32_args, "gv_sumsq": gv_sumsq_args,
     "gv_adamw_ema": gv_adamw_ema_args,
 }
-PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read")
+PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read",
+                 "gv_linear_ln_blocks")
 
 
 class gv_linear_timing_row(C.Structure):
-    _fields_ = [("key", C.c_int32), ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("c_is_f32", C.c_int32), ("splitk", C.c_int32),
-                ("epilogue", C.c_int32), ("launches", C.c_int32), ("seconds", C.c_double), ("flops", C.c_double)]
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int32), ("seconds", C.c_double), ("flops", C.c_double)]
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_POS, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 LN_PARTIAL_BLOCKS = 1024
@@ -118,6 +126,8 @@ def _load():
     lib.gv_linear_timing.restype = C.c_int
     lib.gv_linear_timing_read.argtypes = [C.POINTER(gv_linear_timing_row), C.c_int]
     lib.gv_linear_timing_read.restype = C.c_int
+    lib.gv_linear_ln_blocks.argtypes = [C.c_int32]
+    lib.gv_linear_ln_blocks.restype = C.c_int
     return lib
 
 

@@ -42,8 +42,10 @@
 #define GV_GEMM_NSTAGE 2
 #endif
 #include "gemm_core.h"
+#include "timing.h"
 #include <mutex>
 #include <vector>
+#include <string.h>
 
 namespace {
 
@@ -61,25 +63,14 @@ __global__ __launch_bounds__(PCfg::THREADS, PCfg::THREADS * WGS_PER_CU / 256) vo
     gemm_body<PCfg, TA, TB, OutT, ATOMIC, EPI>(g, (GV_LDS char*)smem_raw);
 }
 
-// ---- live per-kernel timing (gv_linear_timing, include/gipvit.h): HIP events around every
-// GEMM launch on the launch stream, keyed by template instantiation.  Off by default.
-struct TimingRec { int key; hipEvent_t e0, e1; double flops; };
-struct Timing {
-    std::mutex mu;
-    bool on = false;
-    std::vector<TimingRec> recs;
-    std::vector<hipEvent_t> pool;
-    hipEvent_t get() {
-        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
-        hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
-        return e;
-    }
-};
-Timing& timing() { static Timing t; return t; }
-
 template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI>
-constexpr int timing_key() { return (TA ? 1 : 0) | (TB ? 2 : 0) | (sizeof(OutT) == 4 ? 4 : 0) | (ATOMIC ? 8 : 0) | ((EPI & 0xFF) << 4); }
+const char* kernel_name() {
+    static char name[96] = "";
+    if (!name[0])
+        snprintf(name, sizeof(name), "gemm_kernel<%s, %s, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false",
+                 sizeof(OutT) == 4 ? "float" : "bf16", ATOMIC ? "true" : "false", EPI);
+    return name;
+}
 
 template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI = -1>
 int launch(const GemmP& p, hipStream_t s) {
@@ -96,17 +87,9 @@ int launch(const GemmP& p, hipStream_t s) {
     // measured (tools/gemm_lab): with K = 384..2048 one workgroup per item beats a persistent walk
     const int grid = items;
     (void)PERSISTENT_GRID;
-    Timing& tm = timing();
-    if (tm.on) {
-        std::lock_guard<std::mutex> lk(tm.mu);
-        TimingRec r{timing_key<TA, TB, OutT, ATOMIC, EPI>(), tm.get(), tm.get(), 2.0 * p.M * p.N * p.K};
-        (void)hipEventRecord(r.e0, s);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), PCfg::LDS, s, p);
-        (void)hipEventRecord(r.e1, s);
-        tm.recs.push_back(r);
-    } else {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), PCfg::LDS, s, p);
-    }
+    const int th = gvtime::enabled() ? gvtime::begin(kernel_name<TA, TB, OutT, ATOMIC, EPI>(), 2.0 * p.M * p.N * p.K, s) : -1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), PCfg::LDS, s, p);
+    gvtime::end(th, s);
     GV_LAUNCH_CHECK("gv_linear");
     return GV_OK;
 }
@@ -135,6 +118,41 @@ constexpr long WORKSPACE_BYTES = 64L << 20;
 
 extern "C" int64_t gv_linear_workspace_bytes(void) { return WORKSPACE_BYTES; }
 
+// ---- live per-kernel timing (timing.h; gv_linear_timing / gv_linear_timing_read of include/gipvit.h)
+namespace {
+struct TimingRec { const char* name; hipEvent_t e0, e1; double flops; };
+struct Timing {
+    std::mutex mu;
+    bool on = false;
+    std::vector<TimingRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+Timing& timing() { static Timing t; return t; }
+}  // namespace
+
+bool gvtime::enabled() { return timing().on; }
+int gvtime::begin(const char* kernel_name, double flops, hipStream_t s) {
+    Timing& tm = timing();
+    std::lock_guard<std::mutex> lk(tm.mu);
+    if (!tm.on) return -1;
+    TimingRec r{kernel_name, tm.get(), tm.get(), flops};
+    (void)hipEventRecord(r.e0, s);
+    tm.recs.push_back(r);
+    return (int)tm.recs.size() - 1;
+}
+void gvtime::end(int handle, hipStream_t s) {
+    if (handle < 0) return;
+    Timing& tm = timing();
+    std::lock_guard<std::mutex> lk(tm.mu);
+    if (handle < (int)tm.recs.size()) (void)hipEventRecord(tm.recs[handle].e1, s);
+}
+
 extern "C" int gv_linear_timing(int enable) {
     Timing& tm = timing();
     std::lock_guard<std::mutex> lk(tm.mu);
@@ -158,11 +176,11 @@ extern "C" int gv_linear_timing_read(gv_linear_timing_row* rows, int max_rows) {
         e = hipEventElapsedTime(&ms, r.e0, r.e1);
         if (e != hipSuccess) { gv_set_error("gv_linear_timing_read: %s", hipGetErrorString(e)); return (int)e; }
         int i = 0;
-        while (i < n && rows[i].key != r.key) ++i;
+        while (i < n && strcmp(rows[i].name, r.name) != 0) ++i;
         if (i == n) {
             if (n == max_rows) continue;
-            rows[n] = gv_linear_timing_row{r.key, r.key & 1, (r.key >> 1) & 1, (r.key >> 2) & 1, (r.key >> 3) & 1,
-                                           ((r.key >> 4) & 0xFF) == 0xFF ? -1 : ((r.key >> 4) & 0xFF), 0, 0.0, 0.0};
+            memset(&rows[n], 0, sizeof(rows[n]));
+            strncpy(rows[n].name, r.name, sizeof(rows[n].name) - 1);
             ++n;
         }
         rows[i].launches += 1; rows[i].seconds += ms * 1e-3; rows[i].flops += r.flops;

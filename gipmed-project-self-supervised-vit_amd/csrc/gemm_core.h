@@ -14,7 +14,7 @@
 
 namespace gvgemm {
 
-__device__ __attribute__((aligned(256))) unsigned short zero_page[128];   // 256 B of zeros
+static __device__ __attribute__((aligned(256))) unsigned short zero_page[128];   // 256 B of zeros (one copy per translation unit)
 
 struct GemmP {
     const bf16* A; const bf16* B; void* C;

@@ -37,6 +37,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Wave sum without LDS traffic: four DPP row rotations leave every lane of a 16-lane row with the row's sum, four
+// v_readlane pick one lane per row.  (__shfl_xor lowers to ds_bpermute_b32: six dependent LDS round trips per sum --
+// measured 21 us of a 96-us fused GEMM + LayerNorm epilogue at two sums per token row.)  Same value in all lanes.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));   // row_ror:1
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // erf-GELU (nn.GELU default) and its derivative, transcendental-free: both are odd-polynomial
 // fits around 1/2 evaluated at the CLAMPED argument (one v_med3_f32), ~11-13 plain VALU ops per
 // element instead of libm erff's ~40 (a GEMM epilogue is VALU-bound on it):

@@ -1,0 +1,359 @@
+// Full-row "panel" GEMM for the N = 384 products of ViT-S with the LayerNorm that follows them fused into the
+// epilogue -- gv_linear_ln_fwd / gv_linear_ln_bwd (include/gipvit.h).
+//
+// Replaces, per transformer block (vit.pyc@L146-152 Block.forward and its autograd),
+//   forward :  x' = x + Linear(a)  (attn.proj / mlp.fc2, vit.pyc@L98-104, L119-131)  +  the NEXT LayerNorm
+//              (norm2 / the next block's norm1, vit.pyc@L138,142): y = LN(x'), mean, rstd;
+//   backward:  dXn = dY W  (the dX product of mlp.fc1 / attn.qkv)  +  the LayerNorm backward it feeds:
+//              g += dLN/dx, gb = bf16(g), column sums for dgamma / dbeta / the previous Linear's bias gradient.
+// In round 1 these were a 128x128-tile GEMM plus a separate LayerNorm pass; measured there (profiles/r01_*):
+//   * 345 x 3 tiles on 512 workgroup slots = 2.02 rounds -> a third, nearly empty round (423-548 TFLOP/s);
+//   * a 128x128x64 step moves 64 FLOP per byte through the CU's L2 -> LDS path, the bound of that kernel;
+//   * the LayerNorm pass re-reads the f32 row the GEMM epilogue has just written (68 MB per call).
+// Here ONE workgroup (8 waves, 1 per CU) owns BM = 16 * FM consecutive token rows and ALL 384 output columns:
+//   * FM is chosen per launch so that ceil(M / BM) <= 256 * rounds with the last round full (M = 44 160 tokens ->
+//     BM = 176, 251 workgroups, one round);
+//   * a k-step stages (BM + 384) x 64 bf16 = 70 KB for 2 * BM * 384 * 64 FLOP = 121 FLOP per byte (BM = 176);
+//   * the whole output row lives in one workgroup, so the row statistics of the following LayerNorm (forward) or the
+//     row dot products of its backward are taken in the epilogue and the row never makes a second HBM round trip.
+// Wave w owns the 16-column fragments {w, w + 8, w + 16} of every row block (the interleaving keeps a wave's
+// fragments inside one 128-column block of a transposed weight image).  Staging, swizzles, fragment reads and the
+// swapped MFMA roles are those of gemm_core.h (LDS-DMA from inline asm behind hand-counted vmcnt + raw s_barrier).
+// The epilogue transposes the accumulators through a per-pass LDS image and then works one wave per row (full 512-B row
+// segments for every load and store, the arithmetic of layernorm.hip's row kernels, wave sums by DPP); the global rows
+// a pass needs are all requested before the pass's image barrier.
+#include "gemm_core.h"
+#include "timing.h"
+
+namespace {
+
+using namespace gvgemm;
+
+constexpr int PN = 384;              // output columns = the model width this kernel is built for (ViT-S)
+constexpr int PBK = 64;
+constexpr int PNW = 8;               // waves per workgroup
+constexpr int W_BLOCK = 128 * PBK * 2;      // one 128-column block of the weight stage (16 KB)
+constexpr int W_BYTES = 3 * W_BLOCK;
+constexpr int IMG_STRIDE = PN + 4;          // f32 image row stride (+4: conflict-free transposed writes)
+
+template <int FM>
+struct PC {
+    static constexpr int BM = FM * 16;
+    static constexpr int A_PPW = (FM * 2 + 7) / 8;          // 1-KB pieces (8 rows x 128 B) per wave
+    static constexpr int A_ROWS = A_PPW * 8 * 8;            // staged rows (>= BM; surplus rows are clamped duplicates)
+    static constexpr int A_BYTES = A_ROWS * 128;
+    static constexpr int STAGE = A_BYTES + W_BYTES;
+    static constexpr int LDS = 2 * STAGE;
+    static constexpr int IB_FIT = LDS / (IMG_STRIDE * 4) / 16;
+    // 16-row blocks per epilogue pass: bounded by the LDS image and by the registers that hold a pass's prefetched
+    // global rows (forward: the residual row, 6 f32 per lane and row; backward: x and g rows, 12)
+    static constexpr int ib(int want) { return want < (IB_FIT < FM ? IB_FIT : FM) ? want : (IB_FIT < FM ? IB_FIT : FM); }
+    static_assert(IB_FIT >= 1 && LDS <= 160 * 1024, "LDS budget");
+    static_assert(PNW * 3 * PN * 4 <= LDS, "column-sum reduction scratch must fit the ring");
+};
+
+struct PanelP {
+    const bf16* A; const bf16* W; int M, K; long lda, ldw;
+    // forward
+    const float* bias; const float* resid; long ldr; float* out; long ldo;
+    const float* gamma; const float* beta; float eps; bf16* y; float* mean; float* rstd;
+    // backward
+    const float* x; long ldx; float* g; long ldg; bf16* gb; long ldgb; float* partials; int g_init;
+};
+
+enum { MODE_FWD = 0, MODE_BWD = 1 };
+
+template <int FM, bool TB, int MODE>
+__global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
+    using C = PC<FM>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GV_LDS char* smem = (GV_LDS char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li16 = lane & 15, gq = lane >> 4;
+    const int m0 = blockIdx.x * C::BM;
+    const int M = p.M;
+
+    TileSrc<false, C::A_ROWS, PBK, PNW> srcA;
+    TileSrc<TB, 128, PBK, PNW> srcW[3];
+    srcA.setup(p.A, p.lda, m0, M, wave, lane);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, PN, wave, lane);
+
+    const int nt = p.K / PBK;
+    auto issue = [&](int t) {
+        GV_LDS char* st = smem + (t & 1) * C::STAGE;
+        const int k0 = t * PBK;
+        srcA.issue(p.lda, k0, p.K, st, wave);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) srcW[j].issue(p.ldw, k0, p.K, st + C::A_BYTES + j * W_BLOCK, wave);
+    };
+
+    // acc[i][j][r]: row m0 + 16 i + (lane & 15), column 16 (8 j + wave) + 4 (lane >> 4) + r
+    f32x4 acc[FM][3];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue(0);
+
+    for (int t = 0; t < nt; ++t) {
+        wait_vmcnt<0>();                      // my pieces of stage t have landed (nothing younger is in flight yet)
+        __builtin_amdgcn_s_barrier();         // everybody's have; every wave is past its reads of stage t - 1
+        if (t + 1 < nt) issue(t + 1);
+        GV_LDS char* cur = smem + (t & 1) * C::STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fw[3], fa[FM];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fw[j] = read_frag<TB, 128, PBK>(cur + C::A_BYTES + j * W_BLOCK, wave, ks, lane);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = read_frag<false, C::A_ROWS, PBK>(cur, i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue.  The accumulators pass through an LDS image so that the row phase works on whole rows, ONE WAVE PER
+    // ROW (wave w: rows w, w + 8, .. of the pass): every global access is a full 512-B row segment and the row reductions
+    // of the LayerNorm stay inside a wave.  The global rows a pass needs (forward: the residual; backward: x and g, mean,
+    // rstd) are all requested BEFORE the pass's image barrier, so their HBM latency overlaps the image traffic and the
+    // other rows' arithmetic instead of being paid once per row.
+    constexpr int IB = C::ib(MODE == MODE_FWD ? 5 : 3);
+    constexpr int RPW = 2 * IB;                                   // rows per wave and pass
+    GV_LDS float* img = (GV_LDS float*)smem;
+    f32x4 bias4[3];
+    if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            bias4[j] = p.bias ? *(const f32x4*)(p.bias + 16 * (8 * j + wave) + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // per-lane column constants of the row phase: lane owns columns (c * 64 + lane) * 2 + {0, 1}, c = 0..2
+    float gm[3][2], bt[3][2];
+    float s_dg[3][2], s_db[3][2], s_g[3][2];
+    const bool ln = MODE == MODE_BWD || p.gamma != nullptr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int col = (c * 64 + lane) * 2;
+        if (ln) { const f32x2 gv = *(const f32x2*)(p.gamma + col); gm[c][0] = gv[0]; gm[c][1] = gv[1]; }
+        else { gm[c][0] = gm[c][1] = 1.f; }
+        if (MODE == MODE_FWD && ln) { const f32x2 bv = *(const f32x2*)(p.beta + col); bt[c][0] = bv[0]; bt[c][1] = bv[1]; }
+        else { bt[c][0] = bt[c][1] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { s_dg[c][e] = 0.f; s_db[c][e] = 0.f; s_g[c][e] = 0.f; }
+    }
+
+#pragma unroll
+    for (int i0 = 0; i0 < FM; i0 += IB) {
+        const int ni = (FM - i0) < IB ? (FM - i0) : IB;          // compile-time after unrolling
+        // ---- this wave's global rows of the pass (clamped at M: surplus rows load valid memory and are never stored)
+        f32x2 pre_a[RPW][3], pre_b[MODE == MODE_BWD ? RPW : 1][3];
+        float pre_mean[MODE == MODE_BWD ? RPW : 1], pre_rstd[MODE == MODE_BWD ? RPW : 1];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            if (rr < 2 * ni) {
+                int m = m0 + i0 * 16 + wave + 8 * rr;
+                m = m < M ? m : M - 1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int col = (c * 64 + lane) * 2;
+                    if constexpr (MODE == MODE_FWD) {
+                        pre_a[rr][c] = p.resid ? *(const f32x2*)(p.resid + (long)m * p.ldr + col) : f32x2{0.f, 0.f};
+                    } else {
+                        pre_a[rr][c] = *(const f32x2*)(p.x + (long)m * p.ldx + col);
+                        pre_b[rr][c] = p.g_init ? f32x2{0.f, 0.f} : *(const f32x2*)(p.g + (long)m * p.ldg + col);
+                    }
+                }
+                if constexpr (MODE == MODE_BWD) { pre_mean[rr] = p.mean[m]; pre_rstd[rr] = p.rstd[m]; }
+            }
+        }
+        if (i0 == 0) __syncthreads();                             // every wave is past the ring: it is image space now
+        // ---- accumulators -> LDS image [rows of this pass][384 columns] f32
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+            if (ii < ni) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x4 v = acc[i0 + ii][j];
+                    if constexpr (MODE == MODE_FWD) v += bias4[j];
+                    *(GV_LDS f32x4*)(img + (ii * 16 + li16) * IMG_STRIDE + 16 * (8 * j + wave) + gq * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- one wave per row
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            if (rr < 2 * ni) {
+                const int r = wave + 8 * rr;
+                const int m = m0 + i0 * 16 + r;
+                if (m < M) {                                      // wave-uniform
+                    float v[3][2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const f32x2 t2 = *(GV_LDS f32x2*)(img + r * IMG_STRIDE + (c * 64 + lane) * 2);
+                        v[c][0] = t2[0]; v[c][1] = t2[1];
+                    }
+                    if constexpr (MODE == MODE_FWD) {
+                        float* orow = p.out + (long)m * p.ldo;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            v[c][0] += pre_a[rr][c][0]; v[c][1] += pre_a[rr][c][1];
+                            *(f32x2*)(orow + (c * 64 + lane) * 2) = f32x2{v[c][0], v[c][1]};
+                        }
+                        if (ln) {
+                            float sm = 0.f;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) sm += v[c][0] + v[c][1];
+                            const float mean = wave_sum_dpp(sm) * (1.0f / PN);
+                            float q = 0.f;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { const float d0 = v[c][0] - mean, d1 = v[c][1] - mean; q += d0 * d0 + d1 * d1; }
+                            const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * (1.0f / PN) + p.eps);
+                            bf16* yrow = p.y + (long)m * PN;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                *(bf16x2*)(yrow + (c * 64 + lane) * 2) = bf16x2{(bf16)((v[c][0] - mean) * rstd * gm[c][0] + bt[c][0]),
+                                                                                (bf16)((v[c][1] - mean) * rstd * gm[c][1] + bt[c][1])};
+                            if (lane == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
+                        }
+                    } else {
+                        // LayerNorm backward of this row: v = dy (the dX product, still f32)
+                        float* grow = p.g + (long)m * p.ldg;
+                        const float mean = pre_mean[rr], rstd = pre_rstd[rr];
+                        float xh[3][2], wdy[3][2], gv[3][2];
+                        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                gv[c][e] = pre_b[rr][c][e];
+                                xh[c][e] = (pre_a[rr][c][e] - mean) * rstd;
+                                wdy[c][e] = v[c][e] * gm[c][e];
+                                c1 += wdy[c][e];
+                                c2 += wdy[c][e] * xh[c][e];
+                                s_dg[c][e] += v[c][e] * xh[c][e];
+                                s_db[c][e] += v[c][e];
+                            }
+                        c1 = wave_sum_dpp(c1) * (1.0f / PN);
+                        c2 = wave_sum_dpp(c2) * (1.0f / PN);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int col = (c * 64 + lane) * 2;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                gv[c][e] += rstd * (wdy[c][e] - c1 - xh[c][e] * c2);
+                                s_g[c][e] += gv[c][e];
+                            }
+                            *(f32x2*)(grow + col) = f32x2{gv[c][0], gv[c][1]};
+                            if (p.gb) *(bf16x2*)(p.gb + (long)m * p.ldgb + col) = bf16x2{(bf16)gv[c][0], (bf16)gv[c][1]};
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                          // image free for the next pass / the reduction below
+    }
+
+    if constexpr (MODE == MODE_BWD) {
+        // column sums over this workgroup's rows -> partials[blockIdx][3][384] (gv_ln_finalize folds them)
+        GV_LDS float* red = (GV_LDS float*)smem;                  // [8 waves][3][384]
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int col = (c * 64 + lane) * 2 + e;
+                red[(wave * 3 + 0) * PN + col] = s_dg[c][e];
+                red[(wave * 3 + 1) * PN + col] = s_db[c][e];
+                red[(wave * 3 + 2) * PN + col] = s_g[c][e];
+            }
+        __syncthreads();
+        float* outp = p.partials + (long)blockIdx.x * 3 * PN;
+        for (int idx = tid; idx < 3 * PN; idx += 512) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < PNW; ++w) s += red[w * 3 * PN + idx];
+            outp[idx] = s;
+        }
+    }
+}
+
+// smallest supported FM that covers M rows in as few full rounds of 256 workgroups as possible
+constexpr int FM_SET[] = {4, 7, 9, 11, 12};
+int pick_fm(int M) {
+    const int m16 = (M + 15) / 16;
+    const int rounds = (m16 + 256 * 12 - 1) / (256 * 12);
+    const int need = (m16 + 256 * rounds - 1) / (256 * rounds);
+    for (int fm : FM_SET) if (fm >= need) return fm;
+    return 12;
+}
+
+template <int FM, bool TB, int MODE>
+int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
+    auto kern = panel_kernel<FM, TB, MODE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PC<FM>::LDS);
+        if (e != hipSuccess) { gv_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    static char kname[96] = "";
+    if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %s, %d>", FM, TB ? "true" : "false", MODE);
+    const int grid = (p.M + PC<FM>::BM - 1) / PC<FM>::BM;
+    const int th = gvtime::enabled() ? gvtime::begin(kname, 2.0 * p.M * PN * p.K, s) : -1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PC<FM>::LDS, s, p);
+    gvtime::end(th, s);
+    GV_LAUNCH_CHECK(name);
+    return GV_OK;
+}
+
+template <bool TB, int MODE>
+int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
+    switch (pick_fm(p.M)) {
+        case 4: return launch_panel<4, TB, MODE>(p, s, name);
+        case 7: return launch_panel<7, TB, MODE>(p, s, name);
+        case 9: return launch_panel<9, TB, MODE>(p, s, name);
+        case 11: return launch_panel<11, TB, MODE>(p, s, name);
+        default: return launch_panel<12, TB, MODE>(p, s, name);
+    }
+}
+
+}  // namespace
+
+extern "C" int gv_linear_ln_blocks(int32_t M) {
+    if (M <= 0) return 0;
+    return (M + 16 * pick_fm(M) - 1) / (16 * pick_fm(M));
+}
+
+extern "C" int gv_linear_ln_fwd(const gv_linear_ln_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->A && a->W && a->out, GV_E_NULL, "gv_linear_ln_fwd: null operand");
+    GV_REQUIRE(a->N == PN, GV_E_UNSUPPORTED, "gv_linear_ln_fwd: built for N = %d output columns (ViT-S), got %d", PN, a->N);
+    GV_REQUIRE(a->M > 0 && a->K > 0 && a->K % PBK == 0, GV_E_SHAPE, "gv_linear_ln_fwd: need M > 0 and K %% 64 == 0 (got M=%d K=%d)", a->M, a->K);
+    GV_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldo % 2 == 0 && a->ldr % 4 == 0, GV_E_ALIGN, "gv_linear_ln_fwd: leading dimensions misaligned");
+    GV_REQUIRE(gv_aligned(a->A, 16) && gv_aligned(a->W, 16) && gv_aligned(a->out, 16), GV_E_ALIGN, "gv_linear_ln_fwd: A/W/out must be 16-byte aligned");
+    if (a->bias) GV_REQUIRE(gv_aligned(a->bias, 16), GV_E_ALIGN, "gv_linear_ln_fwd: bias misaligned");
+    if (a->resid) GV_REQUIRE(gv_aligned(a->resid, 16), GV_E_ALIGN, "gv_linear_ln_fwd: resid misaligned");
+    if (a->gamma) GV_REQUIRE(a->beta && a->y && a->mean && a->rstd, GV_E_NULL, "gv_linear_ln_fwd: gamma given, so beta / y / mean / rstd are required");
+    PanelP p{};
+    p.A = (const bf16*)a->A; p.W = (const bf16*)a->W; p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw;
+    p.bias = a->bias; p.resid = a->resid; p.ldr = a->ldr; p.out = a->out; p.ldo = a->ldo;
+    p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps; p.y = (bf16*)a->y; p.mean = a->mean; p.rstd = a->rstd;
+    return dispatch_fm<false, MODE_FWD>(p, (hipStream_t)stream, "gv_linear_ln_fwd");
+}
+
+extern "C" int gv_linear_ln_bwd(const gv_linear_ln_bwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->A && a->W && a->x && a->mean && a->rstd && a->gamma && a->g && a->partials, GV_E_NULL, "gv_linear_ln_bwd: null operand");
+    GV_REQUIRE(a->N == PN, GV_E_UNSUPPORTED, "gv_linear_ln_bwd: built for N = %d output columns (ViT-S), got %d", PN, a->N);
+    GV_REQUIRE(a->M > 0 && a->K > 0 && a->K % PBK == 0, GV_E_SHAPE, "gv_linear_ln_bwd: need M > 0 and K %% 64 == 0 (got M=%d K=%d)", a->M, a->K);
+    GV_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldx % 2 == 0 && a->ldg % 2 == 0 && a->ldgb % 2 == 0, GV_E_ALIGN,
+               "gv_linear_ln_bwd: leading dimensions misaligned");
+    GV_REQUIRE(gv_aligned(a->A, 16) && gv_aligned(a->W, 16) && gv_aligned(a->x, 8) && gv_aligned(a->g, 8), GV_E_ALIGN, "gv_linear_ln_bwd: misaligned pointer");
+    GV_REQUIRE(gv_linear_ln_blocks(a->M) <= a->partial_blocks, GV_E_SHAPE, "gv_linear_ln_bwd: partials holds %d blocks, %d needed (gv_linear_ln_blocks)",
+               a->partial_blocks, gv_linear_ln_blocks(a->M));
+    PanelP p{};
+    p.A = (const bf16*)a->A; p.W = (const bf16*)a->W; p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw;
+    p.x = a->x; p.ldx = a->ldx; p.mean = (float*)a->mean; p.rstd = (float*)a->rstd; p.gamma = a->gamma;
+    p.g = a->g; p.ldg = a->ldg; p.gb = (bf16*)a->gb; p.ldgb = a->ldgb; p.partials = a->partials; p.g_init = a->g_init;
+    return dispatch_fm<true, MODE_BWD>(p, (hipStream_t)stream, "gv_linear_ln_bwd");
+}

@@ -245,6 +245,9 @@ class VitRunner:
         a = ARCHS[arch]
         self.arch, self.D, self.depth, self.H, self.img_size = arch, a["embed_dim"], a["depth"], a["num_heads"], img_size
         self.scale = 64 ** -0.5
+        # full-row Linear + LayerNorm kernels (csrc/panel.hip) exist for the ViT-S width; GIPVIT_FUSED_LN=0 keeps the
+        # round-1 pair (128x128-tile GEMM + stand-alone LayerNorm pass) for A/B runs
+        self.fused = self.D == 384 and os.environ.get("GIPVIT_FUSED_LN", "1") != "0"
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
         self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
@@ -279,22 +282,37 @@ class VitRunner:
             ops.cls_rows(xs, W.f("cls_token").view(-1), pos, sg.n_img, sg.N, D)
             ops.linear(sg.patches, W.w("patch_embed.proj.weight").view(D, 768), xs, sg.n_img * sg.P, D, 768,
                        epilogue=E.EPI_BIAS | E.EPI_POS, bias=W.f("patch_embed.proj.bias"), pos=pos, P=sg.P)
+        # D = 384 (ViT-S): proj / fc2 run as full-row products with the residual add AND the LayerNorm that reads the new
+        # row next fused into the epilogue (gv_linear_ln_fwd) -- only block 0's norm1 is a stand-alone pass
+        fused = self.fused
         for i in range(self.depth):
             b, s = f"blocks.{i}.", G.slot(i)
             xa, xb, xc = G.xbuf(2 * i), G.xbuf(2 * i + 1), G.xbuf(2 * i + 2)
             st = G.stats[s]
-            ops.layernorm_fwd(xa, W.f(b + "norm1.weight"), W.f(b + "norm1.bias"), T, D, y=G.xn1[s], mean=st[0], rstd=st[1])
+            if not fused or i == 0:
+                ops.layernorm_fwd(xa, W.f(b + "norm1.weight"), W.f(b + "norm1.bias"), T, D, y=G.xn1[s], mean=st[0], rstd=st[1])
             ops.linear(G.xn1[s], W.w(b + "attn.qkv.weight"), G.qkv[s], T, 3 * D, D, epilogue=E.EPI_BIAS, bias=W.f(b + "attn.qkv.bias"))
             for sg in G.segs:
                 ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s])
-            ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
-                       bias=W.f(b + "attn.proj.bias"), resid=xa)
-            ops.layernorm_fwd(xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), T, D, y=G.xn2[s], mean=st[2], rstd=st[3])
+            if fused:
+                ops.linear_ln_fwd(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, bias=W.f(b + "attn.proj.bias"), resid=xa,
+                                  gamma=W.f(b + "norm2.weight"), beta=W.f(b + "norm2.bias"), y=G.xn2[s], mean=st[2], rstd=st[3])
+            else:
+                ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
+                           bias=W.f(b + "attn.proj.bias"), resid=xa)
+                ops.layernorm_fwd(xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), T, D, y=G.xn2[s], mean=st[2], rstd=st[3])
             ops.linear(G.xn2[s], W.w(b + "mlp.fc1.weight"), G.h[s], T, 4 * D, D,
                        epilogue=E.EPI_BIAS | E.EPI_GELU | (E.EPI_SAVE_PRE if G.save else 0),   # a forward-only group keeps no pre-activation
                        bias=W.f(b + "mlp.fc1.bias"), aux_out=G.hp[s] if G.save else None)
-            ops.linear(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
-                       bias=W.f(b + "mlp.fc2.bias"), resid=xb)
+            if fused:
+                nxt = i + 1 < self.depth
+                nb, ns = f"blocks.{i + 1}.", G.slot(i + 1)
+                ops.linear_ln_fwd(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, 4 * D, bias=W.f(b + "mlp.fc2.bias"), resid=xb,
+                                  gamma=W.f(nb + "norm1.weight") if nxt else None, beta=W.f(nb + "norm1.bias") if nxt else None,
+                                  y=G.xn1[ns] if nxt else None, mean=G.stats[ns][0] if nxt else None, rstd=G.stats[ns][1] if nxt else None)
+            else:
+                ops.linear(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
+                           bias=W.f(b + "mlp.fc2.bias"), resid=xb)
         xl = G.xbuf(2 * self.depth)
         for sg in G.segs:
             r0 = row_off + sg.img0
@@ -353,17 +371,25 @@ class VitRunner:
         # partials buffers rotate; one is rewritten only after the finalize that read it (three calls ago) has run.
         ring, fin_ev, ring_i, last_side = self.partials_ring, [None, None, None], [0], [None]
 
-        def ln_bwd(dy, x, mean, rstd, gamma, gb, d0, d1, d2):
+        def ln_bwd(dy, x, mean, rstd, gamma, gb, d0, d1, d2, dx_of=None):
+            """LayerNorm backward into the residual gradient.  ``dx_of = (dY, W, K)``: the dX product that produces ``dy``
+            runs fused with it (gv_linear_ln_bwd) and ``dy`` never exists in HBM."""
             k = ring_i[0]
             ring_i[0] = (k + 1) % 3
             join(fin_ev[k])
-            ops.layernorm_bwd(dy, x, mean, rstd, gamma, G.g, gb, ring[k], T, D)
+            if dx_of is not None and self.fused:
+                nblk = ops.linear_ln_bwd(dx_of[0], dx_of[1], x, mean, rstd, gamma, G.g, gb, ring[k], T, dx_of[2])
+            else:
+                if dx_of is not None:
+                    ops.linear(dx_of[0], dx_of[1], dy, T, D, dx_of[2], trans_b=True)
+                ops.layernorm_bwd(dy, x, mean, rstd, gamma, G.g, gb, ring[k], T, D)
+                nblk = L.LN_PARTIAL_BLOCKS
             if side is None:
-                ops.ln_finalize(ring[k], L.LN_PARTIAL_BLOCKS, D, d0, d1, d2)
+                ops.ln_finalize(ring[k], nblk, D, d0, d1, d2)
                 return
             e0 = new_event(); e0.record(main); side.wait_event(e0)
             with torch.cuda.stream(side):
-                ops.ln_finalize(ring[k], L.LN_PARTIAL_BLOCKS, D, d0, d1, d2)
+                ops.ln_finalize(ring[k], nblk, D, d0, d1, d2)
                 e1 = new_event(); e1.record(side)
             fin_ev[k] = last_side[0] = e1
 
@@ -375,22 +401,22 @@ class VitRunner:
             join(done_fc1)               # last block's dW_fc1 read dh
             ops.linear(gbs[0], W.w(b + "mlp.fc2.weight"), G.dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
             done_fc2 = dw(gbs[0], G.h[i], W.g(b + "mlp.fc2.weight"), D, 4 * D)
-            ops.linear(G.dh, W.w(b + "mlp.fc1.weight"), G.dxn, T, D, 4 * D, trans_b=True)
             done_fc1 = dw(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, colsum_a=W.g(b + "mlp.fc1.bias"))
             join(done_proj)              # last block's dW_proj read gb2
             ln_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), gbs[1],
-                   W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"))
+                   W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"),
+                   dx_of=(G.dh, W.w(b + "mlp.fc1.weight"), 4 * D))
             # attention
             ops.linear(gbs[1], W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             done_proj = dw(gbs[1], G.o[i], W.g(b + "attn.proj.weight"), D, D)
             join(done_qkv)               # last block's dW_qkv read dqkv
             for sg in G.segs:
                 ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(G.dqkv))
-            ops.linear(G.dqkv, W.w(b + "attn.qkv.weight"), G.dxn, T, D, 3 * D, trans_b=True)
             done_qkv = dw(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, colsum_a=W.g(b + "attn.qkv.bias"))
             join(done_fc2)               # this block's dW_fc2 read gb
             ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gbs[0],
-                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None)
+                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
+                   dx_of=(G.dqkv, W.w(b + "attn.qkv.weight"), 3 * D))
             if on_block_done is not None:
                 # the block's weight gradients are produced by the side stream: report the block from
                 # there, so a data-parallel all-reduce queues behind the dW products and main never waits

@@ -126,17 +126,29 @@ def linear_timing(enable: bool):
 
 
 def linear_timing_read():
-    """Rows {kernel, launches, seconds, flops} per GEMM kernel instantiation since linear_timing(True)."""
+    """Rows {kernel, launches, seconds, flops} per GEMM-class kernel since linear_timing(True)."""
     rows = (L.gv_linear_timing_row * 64)()
     n = L.lib.gv_linear_timing_read(rows, 64)
     if n < 0 or n > 64:
         raise L.GipvitError(f"gv_linear_timing_read: {n}: {L.lib.gv_last_error().decode()}")
-    out = []
-    for r in rows[:n]:
-        name = (f"gemm_kernel<{'true' if r.trans_a else 'false'}, {'true' if r.trans_b else 'false'}, "
-                f"{'float' if r.c_is_f32 else 'bf16'}, {'true' if r.splitk else 'false'}, {r.epilogue}>")
-        out.append({"kernel": name, "launches": r.launches, "seconds": r.seconds, "flops": r.flops})
-    return out
+    return [{"kernel": r.name.decode(), "launches": r.launches, "seconds": r.seconds, "flops": r.flops} for r in rows[:n]]
+
+
+def linear_ln_fwd(A, W, out, M: int, K: int, *, bias=None, resid=None, gamma=None, beta=None, y=None, mean=None, rstd=None, eps: float = 1e-6,
+                  N: int = 384):
+    """out = A W^T + bias + resid (f32) and, with gamma, y / mean / rstd = LayerNorm of the new row; see gv_linear_ln_fwd."""
+    a = L.gv_linear_ln_fwd_args(A.data_ptr(), W.data_ptr(), M, N, K, K, K, _p(bias), _p(resid), N, out.data_ptr(), N,
+                                _p(gamma), _p(beta), eps, _p(y), _p(mean), _p(rstd))
+    L.call("gv_linear_ln_fwd", a, _stream())
+
+
+def linear_ln_bwd(dY, W, x, mean, rstd, gamma, g, gb, partials, M: int, K: int, *, g_init: bool = False, N: int = 384) -> int:
+    """dXn = dY W (W stored [K, N]) fused with the LayerNorm backward it feeds; returns the number of partial blocks
+    written (the n_blocks argument of ln_finalize); see gv_linear_ln_bwd."""
+    a = L.gv_linear_ln_bwd_args(dY.data_ptr(), W.data_ptr(), M, N, K, K, N, x.data_ptr(), N, mean.data_ptr(), rstd.data_ptr(),
+                                gamma.data_ptr(), g.data_ptr(), N, _p(gb), N, partials.data_ptr(), partials.shape[0], int(g_init))
+    L.call("gv_linear_ln_bwd", a, _stream())
+    return L.lib.gv_linear_ln_blocks(M)
 
 
 def attention_fwd(qkv, n_img: int, N: int, H: int, scale: float, o=None, lse=None):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 2
+#define GV_ABI_VERSION 3
 enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
        GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
@@ -176,18 +176,61 @@ typedef struct {
 int64_t gv_linear_workspace_bytes(void);
 int gv_linear(const gv_linear_args* a, void* stream);
 
-/* Live per-kernel timing of gv_linear's GEMM launches (bench.py's roofline leg): while enabled,
- * every GEMM launch is bracketed by two HIP events on the launch stream.  gv_linear_timing(1)
- * clears earlier records and starts recording, gv_linear_timing(0) stops.  _read synchronises
- * on the recorded events and folds them into one row per kernel instantiation
- * gemm_kernel<trans_a, trans_b, c_is_f32 ? float : bf16, splitk, epilogue> (epilogue -1 = the
- * runtime-mask build); returns the number of rows written (<= max_rows) or an error.        */
+/* Live per-kernel timing of the GEMM-class launches (gv_linear, gv_linear_ln_fwd, gv_linear_ln_bwd; bench.py's
+ * roofline leg): while enabled, every such launch is bracketed by two HIP events on the launch stream.
+ * gv_linear_timing(1) clears earlier records and starts recording, gv_linear_timing(0) stops.  _read synchronises
+ * on the recorded events and folds them into one row per kernel (name = the kernel instantiation as rocprofv3
+ * prints it, e.g. "gemm_kernel<true, true, float, true, 16>"); returns the number of rows written (<= max_rows)
+ * or an error.                                                                                                  */
 typedef struct {
-    int32_t key, trans_a, trans_b, c_is_f32, splitk, epilogue, launches;
+    char name[96];
+    int32_t launches;
     double seconds, flops;   /* summed over the launches */
 } gv_linear_timing_row;
 int gv_linear_timing(int enable);
 int gv_linear_timing_read(gv_linear_timing_row* rows, int max_rows);
+
+/* ---- full-row Linear fused with the LayerNorm around it (ViT-S width: N must be 384) --------------------------
+ * One workgroup owns whole output rows, so the row-wise LayerNorm work happens in the GEMM epilogue and the f32
+ * residual row makes one HBM round trip instead of two (csrc/panel.hip).
+ *
+ * fwd -- replaces `x = x + Linear(a)` of Block.forward (attn.proj / mlp.fc2, vit.pyc@L146-152) TOGETHER WITH the
+ * LayerNorm that reads the new x next (norm2 of the block / norm1 of the next block, vit.pyc@L138,142):
+ *     out[m,:] = A[m,:] . W^T + bias + resid[m,:]          (f32; W is the Linear weight [N, K], bf16)
+ *     y[m,:]   = bf16( (out[m,:] - mean[m]) * rstd[m] * gamma + beta ),  mean / rstd of out[m,:] (eps inside the sqrt)
+ * gamma == NULL skips the LayerNorm outputs (last block: the final norm reads CLS rows only); bias / resid optional. */
+typedef struct {
+    const void* A; const void* W;        /* bf16 [M, K] (lda), bf16 [N, K] (ldw)            */
+    int32_t M, N, K; int64_t lda, ldw;
+    const float* bias;                   /* [N] or NULL                                     */
+    const float* resid; int64_t ldr;     /* f32 [M, N] or NULL                              */
+    float* out; int64_t ldo;             /* f32 [M, N]                                      */
+    const float* gamma; const float* beta; float eps;
+    void* y;                             /* bf16 [M, N] compact                             */
+    float* mean; float* rstd;            /* [M]                                             */
+} gv_linear_ln_fwd_args;
+int gv_linear_ln_fwd(const gv_linear_ln_fwd_args* a, void* stream);
+
+/* bwd -- replaces the dX product of the Linear that CONSUMED a LayerNorm output (mlp.fc1 / attn.qkv:
+ * dXn = dY . W with W the Linear weight stored [K = its out features, N = 384]) together with that LayerNorm's
+ * backward (autograd of vit.pyc@L138,142; gv_layernorm_bwd's contract with dy = dXn kept in f32):
+ *     g[m,:] (+)= dLN/dx(dXn[m,:]; x[m,:], mean[m], rstd[m], gamma);   gb[m,:] = bf16(g[m,:])
+ *     partials[b, 0..2, :] = column sums over workgroup b's rows of dXn*xhat, dXn, new g   (gv_ln_finalize folds them:
+ *     dgamma, dbeta, bias gradient of the Linear in front of the residual add)
+ * partials must hold gv_linear_ln_blocks(M) blocks of [3, N] f32.                                                   */
+typedef struct {
+    const void* A; const void* W;        /* bf16 dY [M, K] (lda), bf16 W [K, N] (ldw)       */
+    int32_t M, N, K; int64_t lda, ldw;
+    const float* x; int64_t ldx;         /* f32 [M, N]: the LayerNorm's input rows          */
+    const float* mean; const float* rstd; const float* gamma;
+    float* g; int64_t ldg;               /* f32 [M, N] in/out: residual-stream gradient     */
+    void* gb; int64_t ldgb;              /* bf16 out (may be NULL)                          */
+    float* partials; int32_t partial_blocks;
+    int32_t g_init;                      /* 1: g is treated as 0 on input                   */
+} gv_linear_ln_bwd_args;
+int gv_linear_ln_bwd(const gv_linear_ln_bwd_args* a, void* stream);
+/* workgroups (= partial blocks) a gv_linear_ln_* launch over M rows uses */
+int gv_linear_ln_blocks(int32_t M);
 
 /* ---- attention (vit.pyc@L119-131): softmax(q k^T * scale) v per (image, head)
  * on packed qkv bf16 [n_img*N, 3, H, 64] -> o bf16 [n_img*N, H, 64];

@@ -152,6 +152,76 @@ def test_linear_timing_rows(dev):
     assert o.linear_timing_read() == []
 
 
+# ------------------------------------------------------- full-row Linear + LayerNorm (panel kernel)
+@pytest.mark.parametrize("M,K", [(64, 64), (1380, 384), (44160, 1536), (25216, 384), (2000, 1152), (33000, 128)])
+def test_linear_ln_fwd(dev, M, K):
+    """gv_linear_ln_fwd: out = A W^T + bias + resid exactly (integer operands), and LayerNorm of the new row against
+    F.layer_norm in fp32 (bf16 output tolerance); every supported rows-per-workgroup geometry (M picks FM = 4 .. 12)."""
+    o = ops()
+    N = 384
+    g = torch.Generator().manual_seed(M + K)
+    A, W = ints((M, K), dev, seed=5), ints((N, K), dev, seed=6)
+    bias = torch.randint(-3, 4, (N,), generator=g).float().to(dev)
+    resid = torch.randint(-8, 9, (M, N), generator=g).float().to(dev)
+    gamma, beta = (1.0 + 0.1 * torch.randn(N, generator=g)).to(dev), (0.1 * torch.randn(N, generator=g)).to(dev)
+    out = torch.full((M, N), 7.0, dtype=f32, device=dev)
+    y = torch.empty(M, N, dtype=bf16, device=dev); mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    o.linear_ln_fwd(A, W, out, M, K, bias=bias, resid=resid, gamma=gamma, beta=beta, y=y, mean=mean, rstd=rstd)
+    ref = A.float() @ W.float().t() + bias + resid
+    assert torch.equal(out, ref)                                    # integers: exact in f32 whatever the summation order
+    close(mean, ref.mean(1), 1e-5, 1e-5, "mean")
+    close(rstd, 1.0 / torch.sqrt(ref.var(1, unbiased=False) + 1e-6), 1e-4, 1e-6, "rstd")
+    close(y, torch.nn.functional.layer_norm(ref, (N,), gamma, beta, 1e-6), 8e-3, 8e-3, "ln out")
+    # without LayerNorm outputs / bias / residual
+    out2 = torch.empty(M, N, dtype=f32, device=dev)
+    o.linear_ln_fwd(A, W, out2, M, K)
+    assert torch.equal(out2, A.float() @ W.float().t())
+    # real-valued operands: same numbers as the 128x128 kernel's f32 accumulation up to summation order
+    Ar, Wr = torch.randn(M, K, generator=g).to(dev).to(bf16), (0.05 * torch.randn(N, K, generator=g)).to(dev).to(bf16)
+    rr = torch.randn(M, N, generator=g).to(dev)
+    o.linear_ln_fwd(Ar, Wr, out, M, K, bias=bias, resid=rr, gamma=gamma, beta=beta, y=y, mean=mean, rstd=rstd)
+    ref = Ar.float() @ Wr.float().t() + bias + rr
+    close(out, ref, 1e-4, 1e-3 * math.sqrt(K / 384), "out real")
+    close(y, torch.nn.functional.layer_norm(ref, (N,), gamma, beta, 1e-6), 8e-3, 8e-3, "ln out real")
+
+
+@pytest.mark.parametrize("M,K,g_init", [(64, 64, False), (1380, 1536, False), (44160, 1152, False), (25216, 1536, True), (3000, 384, False)])
+def test_linear_ln_bwd(dev, M, K, g_init):
+    """gv_linear_ln_bwd: dXn = dY W (W stored [K, N]) + the LayerNorm backward it feeds, against autograd in fp32."""
+    o = ops()
+    N = 384
+    g = torch.Generator().manual_seed(M * 3 + K)
+    dY = (0.5 * torch.randn(M, K, generator=g)).to(dev).to(bf16)
+    W = (0.05 * torch.randn(K, N, generator=g)).to(dev).to(bf16)
+    x = (torch.randn(M, N, generator=g) * 1.5 + 0.3).to(dev)
+    gamma, beta = (1.0 + 0.1 * torch.randn(N, generator=g)).to(dev), torch.zeros(N, device=dev)
+    g0 = torch.randn(M, N, generator=g).to(dev)
+    _, mean, rstd = o.layernorm_fwd(x, gamma, beta, M, N)
+    gbuf = g0.clone(); gb = torch.empty(M, N, dtype=bf16, device=dev)
+    partials = torch.full((L().LN_PARTIAL_BLOCKS, 3, N), float("nan"), dtype=f32, device=dev)
+    nb = o.linear_ln_bwd(dY, W, x, mean, rstd, gamma, gbuf, gb, partials, M, K, g_init=g_init)
+    assert nb == L().lib.gv_linear_ln_blocks(M) and 0 < nb <= 256 * ((M + 16 * 12 * 256 - 1) // (16 * 12 * 256))
+    dxn = dY.float() @ W.float()
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (N,), gr, br, 1e-6).backward(dxn)
+    want = xr.grad + (0 if g_init else g0)
+    scale = float(want.abs().max())
+    close(gbuf, want, 1e-3, 2e-4 * scale, "g")
+    close(gb, want, 8e-3, 8e-3 * scale, "gb")
+    outs = [torch.ones(N, device=dev) for _ in range(3)]
+    o.ln_finalize(partials, nb, N, outs[0], outs[1], outs[2])
+    close(outs[0], 1 + gr.grad, 2e-3, 2e-3 * float(gr.grad.abs().max()), "dgamma")
+    close(outs[1], 1 + br.grad, 2e-3, 2e-3 * float(br.grad.abs().max()), "dbeta")
+    close(outs[2], 1 + want.sum(0), 2e-3, 2e-3 * float(want.sum(0).abs().max()), "colsum g")
+    assert bool(torch.isnan(partials[nb:]).all())                   # nothing written beyond the reported block count
+
+
+def test_linear_ln_rejects_other_widths(dev):
+    A = torch.zeros(64, 64, dtype=bf16, device=dev); W = torch.zeros(192, 64, dtype=bf16, device=dev); out = torch.zeros(64, 192, device=dev)
+    with pytest.raises(L().GipvitError, match="N = 384"):
+        ops().linear_ln_fwd(A, W, out, 64, 64, N=192)
+
+
 # ------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("D", [192, 384, 768])
 def test_layernorm_fwd_bwd(dev, D):
