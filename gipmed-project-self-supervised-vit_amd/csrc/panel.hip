@@ -52,6 +52,15 @@ struct PC {
     static_assert(PNW * 3 * PN * 4 <= LDS, "column-sum reduction scratch must fit the ring");
 };
 
+// k-loop variants measured and dropped (round 2, M = 44 160, K = 1536, fused forward; tools/panel_probe.py gives 88 us for
+// the loop below, 71 us with every operand L2-resident, ~29 us of it the HBM-bound epilogue):
+//   * BK = 32, 4-stage ring, the two waves of every SIMD half a step apart (one reads / issues LDS-DMA while its partner
+//     runs MFMAs, two barriers per step): 91 us -- no gain;
+//   * separate rings fed by separate waves (waves 0-3 stream A through 7 stages = 72 KB in flight per CU, waves 4-7 stream
+//     W through 3; one vmcnt queue per operand): 98-101 us -- deeper A prefetch does not help, the 32-deep step costs.
+// So neither the SIMD partners' phase alignment nor the depth of the A stream is what holds the loop at ~55 % of its MFMA
+// time; the LDS fragment traffic (every wave reads all of A: 224 KB per 64-deep step and CU) is the next suspect.
+
 struct PanelP {
     const bf16* A; const bf16* W; int M, K; long lda, ldw;
     // forward
@@ -74,12 +83,18 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
     const int m0 = blockIdx.x * C::BM;
     const int M = p.M;
 
+    // acc[i][j][r]: row m0 + 16 i + (lane & 15), column 16 (8 j + wave) + 4 (lane >> 4) + r
+    f32x4 acc[FM][3];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     TileSrc<false, C::A_ROWS, PBK, PNW> srcA;
     TileSrc<TB, 128, PBK, PNW> srcW[3];
     srcA.setup(p.A, p.lda, m0, M, wave, lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, PN, wave, lane);
-
     const int nt = p.K / PBK;
     auto issue = [&](int t) {
         GV_LDS char* st = smem + (t & 1) * C::STAGE;
@@ -88,15 +103,7 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) srcW[j].issue(p.ldw, k0, p.K, st + C::A_BYTES + j * W_BLOCK, wave);
     };
-
-    // acc[i][j][r]: row m0 + 16 i + (lane & 15), column 16 (8 j + wave) + 4 (lane >> 4) + r
-    f32x4 acc[FM][3];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     issue(0);
-
     for (int t = 0; t < nt; ++t) {
         wait_vmcnt<0>();                      // my pieces of stage t have landed (nothing younger is in flight yet)
         __builtin_amdgcn_s_barrier();         // everybody's have; every wave is past its reads of stage t - 1
@@ -292,9 +299,10 @@ int pick_fm(int M) {
 template <int FM, bool TB, int MODE>
 int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
     auto kern = panel_kernel<FM, TB, MODE>;
+    constexpr int LDS_BYTES = PC<FM>::LDS;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PC<FM>::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { gv_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
@@ -302,7 +310,7 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
     if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %s, %d>", FM, TB ? "true" : "false", MODE);
     const int grid = (p.M + PC<FM>::BM - 1) / PC<FM>::BM;
     const int th = gvtime::enabled() ? gvtime::begin(kname, 2.0 * p.M * PN * p.K, s) : -1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PC<FM>::LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, p);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK(name);
     return GV_OK;
