@@ -49,6 +49,11 @@ gv_linear_ln_bwd_args = _struct("gv_linear_ln_bwd_args", [
     ("A", vp), ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldw", i64), ("x", vp), ("ldx", i64),
     ("mean", vp), ("rstd", vp), ("gamma", vp), ("g", vp), ("ldg", i64), ("gb", vp), ("ldgb", i64), ("partials", vp),
     ("partial_blocks", i32), ("g_init", i32)])
+GV_DW_GROUP_MAX = 4
+gv_dw_problem = _struct("gv_dw_problem", [("dY", vp), ("ldy", i64), ("X", vp), ("ldx", i64), ("dW", vp), ("ldw", i64), ("colsum_dy", vp),
+                                          ("M", i32), ("N", i32)])
+gv_linear_dw_group_args = _struct("gv_linear_dw_group_args", [("prob", gv_dw_problem * GV_DW_GROUP_MAX), ("n", i32), ("K", i32),
+                                                              ("workspace", vp), ("workspace_bytes", i64)])
 gv_attention_fwd_args = _struct("gv_attention_fwd_args", [
     ("qkv", vp), ("o", vp), ("lse", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32)])
 gv_attention_bwd_args = _struct("gv_attention_bwd_args", [
@@ -84,7 +89,7 @@ gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
 ENTRY_POINTS = {
     "gv_patchify": gv_patchify_args, "gv_crop_resize": gv_crop_resize_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
     "gv_colsum_finalize": gv_colsum_finalize_args, "gv_ln_finalize": gv_ln_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
-    "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args,
+    "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args, "gv_linear_dw_group": gv_linear_dw_group_args,
     "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_cls_rows": gv_cls_rows_args,
     "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,

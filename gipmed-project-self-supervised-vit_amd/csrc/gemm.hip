@@ -112,6 +112,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// one launch over up to GV_DW_GROUP_MAX weight-gradient products that reduce over the same token rows: every workgroup
+// runs ONE (problem, tile, k-slice) item of the split-K dW kernel, partial tiles go to the shared slab, one reduce
+// launch folds all problems.  Items are slice-major over the concatenated tile lists, XCD-contiguous like make_walk.
+struct GroupP { GemmP prob[GV_DW_GROUP_MAX]; int n, total_tiles; int tile_base[GV_DW_GROUP_MAX + 1]; };
+
+__global__ __launch_bounds__(PCfg::THREADS, PCfg::THREADS * WGS_PER_CU / 256) void gemm_dw_group_kernel(const GroupP G) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
+    const int qd = nb >> 3, rm = nb & 7;
+    const int b = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + lw;      // bijective XCD-contiguous remap
+    const int slice = b / G.total_tiles, tg = b - slice * G.total_tiles;
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < GV_DW_GROUP_MAX; ++i) q += (i < G.n && tg >= G.tile_base[i]) ? 1 : 0;
+    const GemmP& g = G.prob[q];
+    Walk wk;
+    wk.first = slice * (g.tiles_m * g.tiles_n) + (tg - G.tile_base[q]); wk.stride = 1 << 30; wk.count = 1; wk.mlo = 0; wk.mcnt = g.tiles_m;
+    gemm_body_w<PCfg, true, true, float, true, GV_EPI_ACCUM>(g, (GV_LDS char*)smem_raw, wk);
+}
+
+struct ReduceGroupP { const float* slab[GV_DW_GROUP_MAX]; float* C[GV_DW_GROUP_MAX]; long MN4[GV_DW_GROUP_MAX]; int N4[GV_DW_GROUP_MAX]; long ldc4[GV_DW_GROUP_MAX]; int S; };
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const ReduceGroupP R) {
+    const int q = blockIdx.y;
+    const float* __restrict__ slab = R.slab[q];
+    const long MN4 = R.MN4[q];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (long)gridDim.x * 256) {
+        f32x4 acc = ((const f32x4*)slab)[i];
+        int s2 = 1;
+        for (; s2 + 1 < R.S; s2 += 2) acc += ((const f32x4*)slab)[(long)s2 * MN4 + i] + ((const f32x4*)slab)[(long)(s2 + 1) * MN4 + i];
+        for (; s2 < R.S; ++s2) acc += ((const f32x4*)slab)[(long)s2 * MN4 + i];
+        const long m = i / R.N4[q], n4 = i - m * R.N4[q];
+        f32x4* dst = (f32x4*)R.C[q] + m * R.ldc4[q] + n4;
+        *dst = *dst + acc;
+    }
+}
+
 constexpr long WORKSPACE_BYTES = 64L << 20;
 
 }  // namespace
@@ -292,4 +328,71 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     if (!generic && e == E_BGS) return launch<false, false, bf16, false, E_BGS>(p, s);
     if (!generic && e == E_BG) return launch<false, false, bf16, false, E_BG>(p, s);
     return launch<false, false, bf16, false>(p, s);
+}
+
+extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream) {
+    GV_REQUIRE(a && a->n >= 1 && a->n <= GV_DW_GROUP_MAX, GV_E_SHAPE, "gv_linear_dw_group: 1..%d problems", GV_DW_GROUP_MAX);
+    GV_REQUIRE(a->K > 0 && a->workspace && gv_aligned(a->workspace, 16), GV_E_NULL, "gv_linear_dw_group: K > 0 and an aligned workspace are required");
+    GroupP G{};
+    G.n = a->n;
+    int tiles = 0;
+    for (int q = 0; q < a->n; ++q) {
+        const auto& pr = a->prob[q];
+        GV_REQUIRE(pr.dY && pr.X && pr.dW, GV_E_NULL, "gv_linear_dw_group: null operand in problem %d", q);
+        GV_REQUIRE(pr.M > 0 && pr.N > 0 && pr.M % 8 == 0 && pr.N % 8 == 0, GV_E_SHAPE, "gv_linear_dw_group: M, N must be positive multiples of 8 (problem %d: %d x %d)", q, pr.M, pr.N);
+        GV_REQUIRE(pr.ldy % 8 == 0 && pr.ldx % 8 == 0 && pr.ldw % 4 == 0, GV_E_ALIGN, "gv_linear_dw_group: leading dimensions misaligned (problem %d)", q);
+        GV_REQUIRE(gv_aligned(pr.dY, 16) && gv_aligned(pr.X, 16) && gv_aligned(pr.dW, 16), GV_E_ALIGN, "gv_linear_dw_group: operands must be 16-byte aligned");
+        GemmP& p = G.prob[q];
+        p.A = (const bf16*)pr.dY; p.B = (const bf16*)pr.X; p.C = pr.dW;
+        p.M = pr.M; p.N = pr.N; p.K = a->K; p.lda = pr.ldy; p.ldb = pr.ldx; p.ldc = pr.ldw;
+        p.epi = GV_EPI_ACCUM; p.bias = nullptr; p.resid = nullptr; p.ldr = 0; p.aux_in = nullptr; p.ld_aux = 0; p.aux_out = nullptr;
+        p.pos = nullptr; p.P = 0; p.alpha = 1.f;
+        p.tiles_m = (pr.M + BM - 1) / BM; p.tiles_n = (pr.N + BN - 1) / BN;
+        p.order = 0; p.colsum_a = pr.colsum_dy;
+        G.tile_base[q] = tiles;
+        tiles += p.tiles_m * p.tiles_n;
+    }
+    for (int q = a->n; q <= GV_DW_GROUP_MAX; ++q) G.tile_base[q] = tiles;
+    G.total_tiles = tiles;
+    // as many k-slices as fill the resident workgroup slots once (at least 512 rows per slice)
+    constexpr int SLOTS = 256 * WGS_PER_CU;
+    const int ksteps = (a->K + BK - 1) / BK;
+    int S = SLOTS / tiles > 0 ? SLOTS / tiles : 1;
+    const int maxs = ksteps / (512 / BK) > 0 ? ksteps / (512 / BK) : 1;
+    if (S > maxs) S = maxs;
+    const int per = (ksteps + S - 1) / S;
+    const int ksplit = (ksteps + per - 1) / per;
+    long slab_floats = 0;
+    for (int q = 0; q < a->n; ++q) {
+        GemmP& p = G.prob[q];
+        p.k_per_split = per * BK; p.ksplit = ksplit;
+        p.slab = a->workspace + slab_floats;
+        slab_floats += (long)ksplit * p.M * p.N;
+    }
+    GV_REQUIRE(slab_floats * 4 <= a->workspace_bytes, GV_E_SHAPE, "gv_linear_dw_group: workspace too small (%ld bytes needed)", slab_floats * 4);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCfg::LDS);
+        if (e != hipSuccess) { gv_set_error("gv_linear_dw_group: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    double flops = 0;
+    for (int q = 0; q < a->n; ++q) flops += 2.0 * G.prob[q].M * G.prob[q].N * a->K;
+    const int th = gvtime::enabled() ? gvtime::begin("gemm_dw_group_kernel", flops, s) : -1;
+    hipLaunchKernelGGL(gemm_dw_group_kernel, dim3(tiles * ksplit), dim3(PCfg::THREADS), PCfg::LDS, s, G);
+    gvtime::end(th, s);
+    GV_LAUNCH_CHECK("gv_linear_dw_group");
+    ReduceGroupP R{};
+    long max4 = 0;
+    for (int q = 0; q < a->n; ++q) {
+        R.slab[q] = G.prob[q].slab; R.C[q] = (float*)G.prob[q].C; R.MN4[q] = (long)G.prob[q].M * G.prob[q].N / 4;
+        R.N4[q] = G.prob[q].N / 4; R.ldc4[q] = G.prob[q].ldc / 4;
+        if (R.MN4[q] > max4) max4 = R.MN4[q];
+    }
+    R.S = ksplit;
+    long blocks = (max4 + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)blocks, a->n), dim3(256), 0, s, R);
+    GV_LAUNCH_CHECK("gv_linear_dw_group(reduce)");
+    return GV_OK;
 }

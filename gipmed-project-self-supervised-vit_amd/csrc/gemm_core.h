@@ -239,13 +239,14 @@ template <> struct OutVec<float> { static constexpr int W = 4; };   // 16 B per 
 template <> struct OutVec<bf16> { static constexpr int W = 8; };    // 16 B per lane
 
 // EPI >= 0: compile-time epilogue mask (host guarantees N % 8 == 0); EPI < 0: runtime mask.
+// `wk`: the work list of this workgroup (make_walk for a plain launch; a grouped launch hands every workgroup the one
+// item of the problem it belongs to)
 template <class C, bool TA, bool TB, typename OutT, bool ATOMIC, int EPI>
-__device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
+__device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, const Walk wk) {
     constexpr int BM = C::BM, BN = C::BN, BK = C::BK, FM = C::FM, FN = C::FN, NSTAGE = C::NSTAGE, PD = C::PD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
-    const Walk wk = make_walk<C>(g);
     const int li16 = lane & 15, gq = lane >> 4;
 #ifdef GV_GEMM_STAMPS
     GV_STAMP(t_kernel0);
@@ -669,6 +670,11 @@ __device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
 #endif
         if (it_i + 1 < wk.count) __builtin_amdgcn_s_barrier();
     }
+}
+
+template <class C, bool TA, bool TB, typename OutT, bool ATOMIC, int EPI>
+__device__ __forceinline__ void gemm_body(const GemmP& g, GV_LDS char* smem) {
+    gemm_body_w<C, TA, TB, OutT, ATOMIC, EPI>(g, smem, make_walk<C>(g));
 }
 
 }  // namespace gvgemm

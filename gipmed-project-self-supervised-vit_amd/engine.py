@@ -232,6 +232,10 @@ class VitGroup:
             self.dxn = e((T, D), bf16)
             self.dqkv = e((T, 3 * D), bf16)
             self.do = e((T, D), bf16)
+            # grouped weight gradients (one launch per block, queued on the side stream while the NEXT block runs): the dY
+            # buffers alternate between two sets by block parity, so a block's set stays untouched until its group has run
+            self.gb3, self.gb4 = e((T, D), bf16), e((T, D), bf16)
+            self.dh_b, self.dqkv_b = e((T, 4 * D), bf16), e((T, 3 * D), bf16)
 
     def xbuf(self, j):
         return self.x[j] if self.save else self.x[j % 3]
@@ -248,6 +252,11 @@ class VitRunner:
         # full-row Linear + LayerNorm kernels (csrc/panel.hip) exist for the ViT-S width; GIPVIT_FUSED_LN=0 keeps the
         # round-1 pair (128x128-tile GEMM + stand-alone LayerNorm pass) for A/B runs
         self.fused = self.D == 384 and os.environ.get("GIPVIT_FUSED_LN", "1") != "0"
+        # GIPVIT_GROUP_DW=1: the four weight-gradient products of a block as ONE split-K launch (gv_linear_dw_group).  Measured
+        # (gpurun_out/r2_dwexp.log): the grouped kernel is faster by itself (752 vs 586 TFLOP/s, 28 MB of slab instead of
+        # 4 x 32 MB) but the STEP is slower (16.0 vs 15.6 ms): its 200-us workgroups hold LDS that the main stream's
+        # one-per-CU full-row kernels wait for, while four short launches per block interleave with them.  Off by default.
+        self.group_dw = os.environ.get("GIPVIT_GROUP_DW", "0") == "1"
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
         self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
@@ -329,11 +338,14 @@ class VitRunner:
         D, T, H = self.D, G.T, self.H
         E = L
         ACC = E.EPI_ACCUM
-        G.g.zero_(); G.gb.zero_()
+        grouped = self.group_dw
+        sets = ((G.gb, G.gb2, G.dh, G.dqkv), (G.gb3, G.gb4, G.dh_b, G.dqkv_b))      # per block parity: dY of the MLP / attention half, dh, dqkv
+        gb_first = sets[(self.depth - 1) & 1][0] if grouped else G.gb
+        G.g.zero_(); gb_first.zero_()
         xl = G.x[2 * self.depth]
         for sg in G.segs:
             ops.layernorm_bwd(dfeat[sg.img0:sg.img0 + sg.n_img], sg.rows(xl), sg.fstats[0], sg.fstats[1], W.f("norm.weight"), sg.rows(G.g),
-                              sg.rows(G.gb), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True)
+                              sg.rows(gb_first), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True)
             self._fin3(W.g("norm.weight"), W.g("norm.bias"), W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
         # The weight-gradient GEMMs are off the critical path (nothing in backward consumes dW):
         # they run on a side stream beside the dX chain, so their tiles fill the tail of every
@@ -393,9 +405,56 @@ class VitRunner:
                 e1 = new_event(); e1.record(side)
             fin_ev[k] = last_side[0] = e1
 
+        def dw_group(problems):
+            """all weight gradients of one block in one launch on the side stream; returns the event that marks its end."""
+            if side is None:
+                ops.linear_dw_group(problems, T, self.ws)
+                return None
+            e0 = new_event(); e0.record(main); side.wait_event(e0)
+            with torch.cuda.stream(side):
+                ops.linear_dw_group(problems, T, self.ws)
+                e1 = new_event(); e1.record(side)
+            return e1
+
+        def report(i):
+            if on_block_done is not None:
+                # the block's weight gradients are produced by the side stream: report the block from
+                # there, so a data-parallel all-reduce queues behind the dW products and main never waits
+                if side is None:
+                    on_block_done(i)
+                else:
+                    with torch.cuda.stream(side):
+                        on_block_done(i)
+
+        done_grp = [None, None]
+        for i in reversed(range(self.depth) if grouped else ()):
+            b, st = f"blocks.{i}.", G.stats[i]
+            par = i & 1
+            gb_mlp, gb_att, dh, dqkv = sets[par]
+            gb_next = sets[par ^ 1][0]                    # dY of block i - 1's MLP half
+            join(done_grp[par])                           # block i + 2's group read this parity's buffers
+            ops.linear(gb_mlp, W.w(b + "mlp.fc2.weight"), dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
+            ln_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), gb_att,
+                   W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"),
+                   dx_of=(dh, W.w(b + "mlp.fc1.weight"), 4 * D))
+            ops.linear(gb_att, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
+            for sg in G.segs:
+                ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(dqkv))
+            join(done_grp[par ^ 1])                       # block i + 1's group read gb_next (its MLP-half dY)
+            ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
+                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
+                   dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D))
+            probs = [(gb_mlp, G.h[i], W.g(b + "mlp.fc2.weight"), None),
+                     (dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), W.g(b + "mlp.fc1.bias")),
+                     (gb_att, G.o[i], W.g(b + "attn.proj.weight"), None),
+                     (dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), W.g(b + "attn.qkv.bias"))]
+            done_grp[par] = dw_group(probs)
+            report(i)
+        join(done_grp[0]); join(done_grp[1])
+
         gbs = (G.gb, G.gb2)              # gb: dY of the MLP half, gb2: dY of the attention half
         done_fc1 = done_qkv = done_fc2 = done_proj = None
-        for i in reversed(range(self.depth)):
+        for i in reversed(range(self.depth) if not grouped else ()):
             b, st = f"blocks.{i}.", G.stats[i]
             # MLP
             join(done_fc1)               # last block's dW_fc1 read dh
@@ -417,14 +476,7 @@ class VitRunner:
             ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gbs[0],
                    W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
                    dx_of=(G.dqkv, W.w(b + "attn.qkv.weight"), 3 * D))
-            if on_block_done is not None:
-                # the block's weight gradients are produced by the side stream: report the block from
-                # there, so a data-parallel all-reduce queues behind the dW products and main never waits
-                if side is None:
-                    on_block_done(i)
-                else:
-                    with torch.cuda.stream(side):
-                        on_block_done(i)
+            report(i)
         join(done_qkv)          # every dW product is in (the side stream runs them in order); ws is free again
         join(last_side[0])      # ... and the last finalize
         # token assembly + patch embedding, per segment

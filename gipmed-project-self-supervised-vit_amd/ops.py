@@ -151,6 +151,19 @@ def linear_ln_bwd(dY, W, x, mean, rstd, gamma, g, gb, partials, M: int, K: int, 
     return L.lib.gv_linear_ln_blocks(M)
 
 
+def linear_dw_group(problems, K: int, workspace):
+    """problems: [(dY [K, M] bf16, X [K, N] bf16, dW [M, N] f32 (accumulated), colsum_dy [M] f32 or None), ...] (at most 4) that
+    reduce over the same K token rows -- one split-K launch + one reduce for all of them; see gv_linear_dw_group."""
+    a = L.gv_linear_dw_group_args()
+    a.n, a.K = len(problems), K
+    a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    for q, (dY, X, dW, cs) in enumerate(problems):
+        pr = a.prob[q]
+        pr.dY, pr.ldy, pr.X, pr.ldx, pr.dW, pr.ldw = dY.data_ptr(), dY.shape[1], X.data_ptr(), X.shape[1], dW.data_ptr(), dW.shape[1]
+        pr.colsum_dy, pr.M, pr.N = _p(cs), dY.shape[1], X.shape[1]
+    L.call("gv_linear_dw_group", a, _stream())
+
+
 def attention_fwd(qkv, n_img: int, N: int, H: int, scale: float, o=None, lse=None):
     dev = qkv.device
     o = torch.empty(n_img * N, H * 64, dtype=bf16, device=dev) if o is None else o

@@ -176,6 +176,27 @@ typedef struct {
 int64_t gv_linear_workspace_bytes(void);
 int gv_linear(const gv_linear_args* a, void* stream);
 
+/* Weight gradients of several Linears that reduce over the SAME token rows (one transformer block: attn.qkv, attn.proj,
+ * mlp.fc1, mlp.fc2; autograd of vit.pyc@L98-104, L119-131) in ONE launch:  dW_q[M_q, N_q] += dY_q^T X_q over K rows, and
+ * colsum_dy_q[m] += sum_k dY_q[k, m] (the bias gradient) where given.  Split-K fills the chip ONCE for the whole group
+ * instead of once per product: 108 tiles x 4 slices for a ViT-S block instead of 4 x (9..36 tiles x 14..56 slices), so the
+ * partial-tile slab traffic drops from 4 x 32 MB to 28 MB and one reduce launch serves all products.
+ * workspace: f32 scratch, gv_linear_workspace_bytes() big.                                                             */
+#define GV_DW_GROUP_MAX 4
+typedef struct {
+    const void* dY; int64_t ldy;     /* bf16 [K, M]  (rows = tokens)                         */
+    const void* X;  int64_t ldx;     /* bf16 [K, N]                                          */
+    float* dW; int64_t ldw;          /* f32 [M, N], accumulated into                         */
+    float* colsum_dy;                /* f32 [M] or NULL, accumulated into                    */
+    int32_t M, N;
+} gv_dw_problem;
+typedef struct {
+    gv_dw_problem prob[GV_DW_GROUP_MAX];
+    int32_t n, K;
+    float* workspace; int64_t workspace_bytes;
+} gv_linear_dw_group_args;
+int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream);
+
 /* Live per-kernel timing of the GEMM-class launches (gv_linear, gv_linear_ln_fwd, gv_linear_ln_bwd; bench.py's
  * roofline leg): while enabled, every such launch is bracketed by two HIP events on the launch stream.
  * gv_linear_timing(1) clears earlier records and starts recording, gv_linear_timing(0) stops.  _read synchronises

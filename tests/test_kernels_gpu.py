@@ -216,6 +216,27 @@ def test_linear_ln_bwd(dev, M, K, g_init):
     assert bool(torch.isnan(partials[nb:]).all())                   # nothing written beyond the reported block count
 
 
+def test_linear_dw_group_exact(dev):
+    """gv_linear_dw_group: the four weight gradients of a block in one split-K launch == four dY^T X products (+ column sums),
+    bit exact on integer data; accumulates into dW."""
+    o = ops()
+    T = 3000
+    shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]
+    probs, refs = [], []
+    for q, (Mq, Nq) in enumerate(shapes):
+        dY, X = ints((T, Mq), dev, seed=10 + q), ints((T, Nq), dev, seed=20 + q)
+        dW = torch.full((Mq, Nq), float(q), dtype=f32, device=dev)
+        cs = torch.full((Mq,), 2.0, dtype=f32, device=dev) if q % 2 else None
+        probs.append((dY, X, dW, cs))
+        refs.append((q + dY.float().t() @ X.float(), None if cs is None else 2.0 + dY.float().sum(0)))
+    ws = torch.empty(L().lib.gv_linear_workspace_bytes() // 4, dtype=f32, device=dev)
+    o.linear_dw_group(probs, T, ws)
+    for (dY, X, dW, cs), (rw, rc) in zip(probs, refs):
+        assert torch.equal(dW, rw)
+        if cs is not None:
+            assert torch.equal(cs, rc)
+
+
 def test_linear_ln_rejects_other_widths(dev):
     A = torch.zeros(64, 64, dtype=bf16, device=dev); W = torch.zeros(192, 64, dtype=bf16, device=dev); out = torch.zeros(64, 192, device=dev)
     with pytest.raises(L().GipvitError, match="N = 384"):
