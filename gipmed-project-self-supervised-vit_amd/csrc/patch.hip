@@ -56,6 +56,14 @@ __global__ __launch_bounds__(256) void patchify_kernel(gv_patchify_args a, int P
         const int c = j % 3;
         px[c][j / 3] = v * (c == 0 ? s0 : c == 1 ? s1 : s2) + (c == 0 ? o0 : c == 1 ? o1 : o2);
     }
+    if (a.fill) {
+        const float* f = a.fill + (long)tile * 8;
+        if (f[7] != 0.f && (float)y >= f[0] && (float)y < f[1]) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((float)(x + i) >= f[2] && (float)(x + i) < f[3]) { px[0][i] = f[4]; px[1][i] = f[5]; px[2][i] = f[6]; }
+        }
+    }
     bf16* out = (bf16*)a.patches + ip * 768 + py * 16;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

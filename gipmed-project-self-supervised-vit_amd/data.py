@@ -206,11 +206,16 @@ class TileFolder:
     def fill(self, out: np.ndarray, targets: np.ndarray):
         """Read the next batch into ``out`` [B, H, W, 3] u8 / ``targets`` [B, 1] i64; returns futures to wait on."""
         items = self.plan()
-        futs = []
-        for j, (path, y) in enumerate(items):
+        for j, (_, y) in enumerate(items):
             targets[j, 0] = y
-            futs.append(self.pool.submit(self._read_one, path, out[j]))
-        return futs
+        # one task per reader thread (a strided share of the batch), not one per tile: the launch loop that calls this has
+        # ~16 ms per step for ~1000 kernel launches, and 64 submissions + 64 waits cost it more than 1 ms
+        nw = min(self.pool._max_workers, len(items))
+        return [self.pool.submit(self._read_share, items, out, w, nw) for w in range(nw)]
+
+    def _read_share(self, items, out, w, nw):
+        for j in range(w, len(items), nw):
+            self._read_one(items[j][0], out[j])
 
     def _read_one(self, path, dst):
         if self.transform is None or not getattr(self.transform, "ops", True):
@@ -321,10 +326,21 @@ class DevicePrefetcher:
     for the GIL with it: measured 26.6 vs 18.5 ms/step in round 1).  ``'Data'`` / ``'Target'`` come back as device
     tensors valid until the next-but-one ``next()``."""
 
-    def __init__(self, source, device, tile_shape: Tuple[int, int, int, int]):
+    def __init__(self, source, device, tile_shape: Tuple[int, int, int, int], augmenter=None):
+        """``augmenter`` (gipvit.augment.TileAugmenter): its per-tile draws for the batch are made while the batch is
+        staged and travel in the same pinned slot / on the same copy stream (``'AugParams'``, ``'Fill'`` in the batch dict);
+        a pageable copy issued from the launch loop would block it behind the tile transfer."""
         self.src, self.dev = source, torch.device(device)
         self.copy = torch.cuda.Stream(self.dev)
         B = tile_shape[0]
+        self.aug = augmenter
+        if augmenter is not None:
+            rec = augmenter._DT.itemsize
+            self.pin_a = [torch.empty(B * rec, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.pin_f = [torch.zeros(B, 8, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self.d_a = [torch.empty(B * rec, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+            self.d_f = [torch.zeros(B, 8, dtype=torch.float32, device=self.dev) for _ in range(2)]
+            self.has_fill = [False, False]
         self.pin = [torch.empty(tile_shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.pin_t = [torch.empty((B, 1), dtype=torch.int64).pin_memory() for _ in range(2)]
         self.dbuf = [torch.empty(tile_shape, dtype=torch.uint8, device=self.dev) for _ in range(2)]
@@ -348,6 +364,12 @@ class DevicePrefetcher:
             if mb is None:
                 return False
             self.pin[k].copy_(mb["Data"]); self.pin_t[k].copy_(mb["Target"].view(-1, 1))
+        if self.aug is not None:
+            packed, fill = self.aug.pack_batch(self.aug.sample_batch(self.pin[k].shape[0]))
+            self.pin_a[k].numpy()[:] = packed
+            self.has_fill[k] = fill is not None
+            if fill is not None:
+                self.pin_f[k].numpy()[:] = fill
         return True
 
     def _h2d(self, k: int):
@@ -359,6 +381,10 @@ class DevicePrefetcher:
         with torch.cuda.stream(self.copy):
             self.dbuf[k].copy_(self.pin[k], non_blocking=True)
             self.dtgt[k].copy_(self.pin_t[k], non_blocking=True)
+            if self.aug is not None:
+                self.d_a[k].copy_(self.pin_a[k], non_blocking=True)
+                if self.has_fill[k]:
+                    self.d_f[k].copy_(self.pin_f[k], non_blocking=True)
             self.ready[k].record(self.copy)
 
     def __iter__(self):
@@ -376,7 +402,10 @@ class DevicePrefetcher:
         k = 0
         while valid[k]:
             torch.cuda.current_stream().wait_event(self.ready[k])
-            yield {"Data": self.dbuf[k], "Target": self.dtgt[k]}
+            mb = {"Data": self.dbuf[k], "Target": self.dtgt[k]}
+            if self.aug is not None:
+                mb["AugParams"], mb["Fill"] = self.d_a[k], (self.d_f[k] if self.has_fill[k] else None)
+            yield mb
             # the consumer has launched its step on batch i (slot k); batch i+1's reads ran meanwhile
             ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
             self.freed[k] = ev

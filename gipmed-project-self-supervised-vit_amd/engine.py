@@ -270,16 +270,17 @@ class VitRunner:
         self._events: List[torch.cuda.Event] = []
 
     # ---- forward: tiles -> CLS features written into feats[row_off + seg.img0 ...]
-    def forward(self, W: Weights, G: VitGroup, tiles_u8, windows, mean, std, feats, row_off: int = 0):
+    def forward(self, W: Weights, G: VitGroup, tiles_u8, windows, mean, std, feats, row_off: int = 0, fill=None):
         """windows: one list of (y0, x0) crop origins per segment; tiles_u8: one NHWC u8 tensor for all
-        segments, or one per segment (pre-cut crops: each with the single window (0, 0))."""
+        segments, or one per segment (pre-cut crops: each with the single window (0, 0)).  ``fill``: per-tile normalised
+        fill boxes of the augmentation (gipvit.augment: Cutout after Normalize, MeanPixelRegularization), f32 [n_tiles, 8]."""
         D, T, H = self.D, G.T, self.H
         E = L
         pos_full = W.f("pos_embed").view(-1, D)
         x0 = G.xbuf(0)
         for k, (sg, wins) in enumerate(zip(G.segs, windows)):
             src = tiles_u8[k] if isinstance(tiles_u8, (list, tuple)) else tiles_u8
-            ops.patchify(src, wins, sg.crop, mean, std, out=sg.patches)
+            ops.patchify(src, wins, sg.crop, mean, std, out=sg.patches, fill=fill)
             if sg.pos is None:
                 pos = pos_full
             else:   # interpolate_pos_encoding: row 0 = cls pos, rows 1.. = M @ pos[1:]
@@ -695,7 +696,7 @@ class DinoEngine:
         vals[L.HYP_STUDENT_TEMP] = self.ts
         ops.store_f32(self.hyper, vals)
 
-    def forward_backward(self, tiles_u8: torch.Tensor, micro: Tuple[int, int] = (0, 1), boxes=None):
+    def forward_backward(self, tiles_u8: torch.Tensor, micro: Tuple[int, int] = (0, 1), boxes=None, fill=None):
         """teacher fwd (global crops) -> student fwd (all crops) -> loss -> backward.
         Leaves gradients in arena.g, loss in self.loss, center_sum.  ``micro = (j, n)``: this is
         micro-batch j of n (gradient accumulation): gradients, loss and centre sums add up over
@@ -707,6 +708,8 @@ class DinoEngine:
         if first:
             a.g.zero_()
         t_src, t_win, s_src, s_win = tiles_u8, [self.gwins], tiles_u8, self.s_wins
+        if boxes is not None and fill is not None:
+            raise ValueError("fill boxes are tile coordinates: they cannot be combined with re-cut random crops (boxes)")
         if boxes is not None:
             # random-resized crops (multicrop.MultiCropSampler): cut on the device, then every crop is its own
             # "tile" with the single window (0, 0); rows stay crop-major like the fixed windows
@@ -728,13 +731,13 @@ class DinoEngine:
             main = torch.cuda.current_stream()
             self._ev_fork.record(main); side.wait_event(self._ev_fork)
             with torch.cuda.stream(side):
-                self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats)
+                self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats, fill=fill)
                 self.head.forward(self.tH, self.wn_t, self.hb_t)
                 self._ev_join.record(side)
         else:
-            self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats)
+            self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats, fill=fill)
             self.head.forward(self.tH, self.wn_t, self.hb_t)
-        self.vit.forward(self.sW, self.g_stu, s_src, s_win, self.mean, self.std, self.hb_s.feats)
+        self.vit.forward(self.sW, self.g_stu, s_src, s_win, self.mean, self.std, self.hb_s.feats, fill=fill)
         self.head.forward(self.sH, self.wn_s, self.hb_s)
         if side is not None:
             main.wait_event(self._ev_join)
@@ -820,13 +823,13 @@ class DinoEngine:
             self._n_micro = 1
         return self.loss
 
-    def step(self, tiles_u8: torch.Tensor, boxes=None, **sched) -> torch.Tensor:
+    def step(self, tiles_u8: torch.Tensor, boxes=None, fill=None, **sched) -> torch.Tensor:
         """One full training step on [B, tile, tile, 3] uint8 NHWC tiles.  Returns the
         (device, un-synchronised) loss tensor.  ``boxes``: (global, local) int32 device tensors from
         multicrop.MultiCropSampler.sample -- random-resized crops instead of the fixed parity windows."""
         assert tiles_u8.shape == (self.B, self.tile, self.tile, 3) and tiles_u8.dtype == torch.uint8
         self.set_hyper(**sched)
-        self.forward_backward(tiles_u8, boxes=boxes)
+        self.forward_backward(tiles_u8, boxes=boxes, fill=fill)
         self.optimizer_step()
         return self.loss
 
@@ -886,17 +889,17 @@ class SupervisedEngine:
     def grads(self):
         return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
 
-    def forward(self, tiles_u8, ema: bool = False):
+    def forward(self, tiles_u8, ema: bool = False, fill=None):
         """Inference / features: returns (logits f32 [B,C], CLS features bf16 [B,D]); ``ema``: with the EMA weights."""
         B, C, D, W = self.B, self.C, self.D, (self.Wema if ema else self.W)
-        self.vit.forward(W, self.grp, tiles_u8, [[(0, 0)]], self.mean, self.std, self.feats)
+        self.vit.forward(W, self.grp, tiles_u8, [[(0, 0)]], self.mean, self.std, self.feats, fill=fill)
         ops.small_matmul(self.feats, W.f("head.weight"), self.logits, B, C, D, sam=D, sak=1, sbk=1, sbn=D, bias=W.f("head.bias"))
         return self.logits, self.feats
 
-    def forward_backward(self, tiles_u8, target):
+    def forward_backward(self, tiles_u8, target, fill=None):
         B, C, D, W = self.B, self.C, self.D, self.W
         self.arena.g.zero_()
-        self.forward(tiles_u8)
+        self.forward(tiles_u8, fill=fill)
         ops.softmax_lsce(self.logits, target.view(-1), self.loss, self.dlogits, self.prob, B, C, self.smoothing)
         # head backward: dW = dlogits^T f, db = colsum(dlogits), df = dlogits W
         ops.small_matmul(self.dlogits, self.feats, W.g("head.weight"), C, D, B, sam=1, sak=C, sbk=D, sbn=1, accumulate=True)
@@ -927,9 +930,9 @@ class SupervisedEngine:
             sl = slice(lo, hi)
             ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], *tt(sl), hi - lo, weight_decay=wd, **kw)
 
-    def step(self, tiles_u8, target, lr=None):
+    def step(self, tiles_u8, target, lr=None, fill=None):
         assert tiles_u8.dtype == torch.uint8 and target.dtype == torch.int64
-        self.forward_backward(tiles_u8, target)
+        self.forward_backward(tiles_u8, target, fill=fill)
         self.optimizer_step(lr)
         return self.loss
 

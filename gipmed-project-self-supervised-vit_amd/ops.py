@@ -25,8 +25,26 @@ def _chk(t: torch.Tensor, dtype, name: str):
         raise TypeError(f"{name}: expected a {dtype} device tensor, got {t.dtype} on {t.device}")
 
 
+def augment(tiles_u8: torch.Tensor, params: torch.Tensor, stats: torch.Tensor, ztable: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Apply one augmentation record per tile on the device (gv_augment).  params: uint8 device tensor holding n packed
+    gv_augment_params records (gipvit.augment packs them); stats: int64 device scratch [n]; ztable: f32 [1024]."""
+    _chk(tiles_u8, torch.uint8, "tiles")
+    n, H, W, _ = tiles_u8.shape
+    assert params.is_cuda and params.dtype == torch.uint8 and params.numel() == n * C_sizeof_augment_params() and stats.numel() >= n
+    if out is None:
+        out = torch.empty_like(tiles_u8)
+    a = L.gv_augment_args(tiles_u8.data_ptr(), out.data_ptr(), params.data_ptr(), stats.data_ptr(), ztable.data_ptr(), n, H, W)
+    L.call("gv_augment", a, _stream())
+    return out
+
+
+def C_sizeof_augment_params() -> int:
+    import ctypes
+    return ctypes.sizeof(L.gv_augment_params)
+
+
 def patchify(tiles_u8: torch.Tensor, windows: Sequence[Sequence[int]], crop: int, mean, std,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, fill: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tiles_u8 [n_tiles, H, W, 3] u8 NHWC; windows [(y0, x0)] of side ``crop``.
     Returns bf16 patches [(len(windows) * n_tiles) * (crop/16)^2, 768], images crop-major."""
     _chk(tiles_u8, torch.uint8, "tiles")
@@ -43,6 +61,9 @@ def patchify(tiles_u8: torch.Tensor, windows: Sequence[Sequence[int]], crop: int
         a.win_y[i], a.win_x[i] = int(y), int(x)
     for c in range(3):
         a.mean[c], a.std[c] = float(mean[c]), float(std[c])
+    if fill is not None:        # f32 [n_tiles, 8] device: normalised fill boxes (Cutout after Normalize, MeanPixelRegularization)
+        assert fill.is_cuda and fill.dtype == f32 and fill.shape == (n_tiles, 8) and fill.is_contiguous()
+        a.fill = fill.data_ptr()
     L.call("gv_patchify", a, _stream())
     return out
 

@@ -8,12 +8,13 @@ uint8 NHWC -- ToTensor's /255 and Normalize are fused into the patchify kernel o
 (PIL.Image or uint8 HxWx3 array) to a uint8 HxWx3 numpy array and carries ``.mean`` / ``.std``.
 
 As in the reference (transformations.py:199-200) a ``transform_type`` that is not a known
-string is used AS the transform: that is the user's augmentation hook.  Of the named
-recipes only the geometric, byte-exact ones run here (flips, 90-degree rotations, the
-'none' recipe); the PIL colour / blur / affine / cutout recipes are CPU augmentation outside
-this build's scope and raise NotImplementedError instead of silently
-doing something else.  The DINO random-resized crops + flips are cut on the device instead
-(gipvit.multicrop.MultiCropSampler + gv_crop_resize).
+string is used AS the transform: that is the user's augmentation hook.  The named recipes
+(flip, rvf, cbnfrsc, cbnfrs, pcbnfrsc, pcbnfrs, cbnfr, bnfrsc, bnfrs, frs, aug_receptornet) run ON THE DEVICE:
+the returned object carries ``device_recipe`` and the driver hands the tiles, once they are in HBM, to
+``gipvit.augment.TileAugmenter`` (gv_augment: colour jitter, blur, noise, flips / rotations, zoom, cutout --
+byte-exact against oracle/augment_oracle.py, which is pinned against PIL).  Called directly on a host tile the
+object applies only the flips / 90-degree rotations ('flip', 'rvf'); the other recipes have no CPU path.
+The DINO random-resized crops + flips are cut on the device too (gipvit.multicrop.MultiCropSampler + gv_crop_resize).
 """
 from __future__ import annotations
 
@@ -36,9 +37,8 @@ STD = {
     "Imagenet": [0.229, 0.224, 0.225],
     "Amir": [0.0787, 0.1751, 0.1125],
 }
-GEOMETRIC = {"none", "flip", "rvf"}          # recipes made only of flips / 90-degree rotations
-CPU_ONLY = {"cbnfrsc", "cbnfrs", "wcfrs", "hedcfrs", "pcbnfrsc", "pcbnfrs", "c_0_05_bnfrsc", "c_0_05_bnfrs", "bnfrsc", "bnfrs",
-            "aug_receptornet", "crs", "frs", "fn", "cbnfr"}
+GEOMETRIC = {"none", "flip", "rvf"}          # recipes made only of flips / 90-degree rotations: also callable on the host
+DEVICE_RECIPES = {"flip", "rvf", "cbnfrsc", "cbnfrs", "pcbnfrsc", "pcbnfrs", "cbnfr", "bnfrsc", "bnfrs", "frs", "aug_receptornet"}
 
 
 def _to_u8(img) -> np.ndarray:
@@ -51,11 +51,15 @@ def _to_u8(img) -> np.ndarray:
 class TileTransform:
     """Callable tile -> uint8 HxWx3 array; ``mean`` / ``std`` feed the fused GPU normalise."""
 
-    def __init__(self, ops: Sequence[Callable[[np.ndarray, np.random.Generator], np.ndarray]], mean, std, tile_size: int, seed=None):
+    def __init__(self, ops: Sequence[Callable[[np.ndarray, np.random.Generator], np.ndarray]], mean, std, tile_size: int, seed=None,
+                 device_recipe: Optional[str] = None, color_param: float = 0.1):
         self.ops, self.mean, self.std, self.tile_size = list(ops), tuple(mean), tuple(std), tile_size
         self.rng = np.random.default_rng(seed)
+        self.device_recipe, self.color_param = device_recipe, color_param      # for gipvit.augment.TileAugmenter
 
     def __call__(self, img) -> np.ndarray:
+        if self.device_recipe is not None and self.device_recipe not in GEOMETRIC:
+            raise NotImplementedError(f"recipe '{self.device_recipe}' runs on the device (gipvit.augment.TileAugmenter / gv_augment); it has no CPU path")
         a = _to_u8(img)
         for op in self.ops:
             a = op(a, self.rng)
@@ -87,15 +91,12 @@ def define_transformations(transform_type: Union[str, Callable], train: bool, ti
             except AttributeError:
                 pass
         return transform_type
-    if transform_type in CPU_ONLY and train:
-        raise NotImplementedError(
-            f"transform_type '{transform_type}' is a PIL colour/blur/affine recipe (reference transformations.py:131-197): CPU "
-            "augmentation is outside this build's hot path -- pass a callable as transform_type, or use 'none' / 'flip' / 'rvf'")
+    if transform_type not in DEVICE_RECIPES | {"none"}:
+        raise ValueError(f"unknown transform_type '{transform_type}' (named recipes: {sorted(DEVICE_RECIPES)}; pass a callable for a custom one)")
     ops = []
     if train and transform_type == "flip":
         ops = [_hflip, _vflip]
     elif train and transform_type == "rvf":
         ops = [_rot90, _vflip]
-    elif transform_type not in GEOMETRIC | CPU_ONLY:
-        raise ValueError(f"unknown transform_type '{transform_type}'")
-    return TileTransform(ops, mean, std, tile_size, seed)
+    return TileTransform(ops, mean, std, tile_size, seed, device_recipe=transform_type if (train and transform_type != "none") else None,
+                         color_param=color_param)

@@ -63,6 +63,10 @@ typedef struct {
     float mean[3], std[3];
     /* image index i -> tile i % n_tiles, window i / n_tiles (crop-major)     */
     int32_t n_tiles;
+    /* optional device f32 [n_tiles][8] = {y0, y1, x0, x1, v_r, v_g, v_b, on}: pixels of tile t inside the box take the
+     * NORMALISED value v_c -- Cutout applied after Normalize (transformations.py:206-207: zeros) and
+     * MyMeanPixelRegularization (91-100: the whole tile becomes one colour) are not uint8 pixel values          */
+    const float* fill;
 } gv_patchify_args;
 int gv_patchify(const gv_patchify_args* a, void* stream);
 
@@ -80,6 +84,33 @@ typedef struct {
     int32_t n_crops, n_tiles, tile_h, tile_w, out_size;
 } gv_crop_resize_args;
 int gv_crop_resize(const gv_crop_resize_args* a, void* stream);
+
+/* ---- tile augmentation on the device (replaces the CPU / PIL recipes of transformations.py:131-197 on tiles that are
+ * already in HBM).  One parameter record per tile, drawn on the host; operations in reference order:
+ *   colour ops in `order` (0 brightness, 1 contrast, 2 saturation, 3 hue: torchvision ColorJitter on PIL images, PIL's
+ *   float32 blend with truncation; hue = +`hue` on the H byte of PIL's HSV image) -> Gaussian blur 3x3 (float32, reflect
+ *   padding, round half to even; kc / ks = centre / side weight of the 1-D kernel) -> Gaussian noise x/255 + sigma * z,
+ *   clip, (255 x) truncated (transformations.py:71-88; z = ztable[murmur3(seed, pixel, channel) >> 22]) -> dihedral element
+ *   d4 (bit 0 transpose, bit 1 mirror rows, bit 2 mirror columns: any sequence of flips / MyRotation, 48-56) -> NEAREST
+ *   zoom about the centre in 16.16 fixed point (RandomAffine(degrees=0, scale), PIL semantics) -> black box `cut`
+ *   (Cutout on the [0, 1] tensor, 10-45).  Byte-exact against oracle/augment_oracle.py.
+ * stats: device scratch u64 [n] (zeroed by the call); ztable: device f32 [1024], quantiles of N(0, 1).                  */
+typedef struct {
+    int32_t n_color; int32_t order[4];
+    float bf, cf, sf; int32_t hue;
+    int32_t blur; float kc, ks;
+    float sigma; uint32_t seed;
+    int32_t d4;
+    int32_t zoom, a0, a2;
+    int32_t cut[4];              /* y0, y1, x0, x1 in output coordinates; empty when y0 >= y1            */
+} gv_augment_params;
+typedef struct {
+    const uint8_t* tiles; uint8_t* out;       /* u8 [n, H, W, 3] NHWC, out != tiles                     */
+    const gv_augment_params* params;          /* device [n]                                             */
+    uint64_t* stats; const float* ztable;
+    int32_t n, H, W;
+} gv_augment_args;
+int gv_augment(const gv_augment_args* a, void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm(D, eps=1e-6); vit.pyc@L138,142,195) -------
  * fwd: x f32 rows -> y bf16 rows (+ mean, rstd f32 per row).

@@ -165,8 +165,13 @@ def test_transformations_hook_and_tile_files(tmp_path):
     assert t.mean == (0.8998, 0.8253, 0.9357) and T.define_transformations("none", False, 256, norm_type="Imagenet").std == (0.229, 0.224, 0.225)
     hook = lambda img: np.asarray(img)[::-1]
     assert T.define_transformations(hook, True, 256) is hook          # non-string = the user's transform (transformations.py:199-200)
+    dev_t = T.define_transformations("pcbnfrsc", True, 256, color_param=0.2)
+    assert dev_t.device_recipe == "pcbnfrsc" and dev_t.color_param == 0.2      # runs on the device (gipvit.augment), no CPU path
     with pytest.raises(NotImplementedError):
-        T.define_transformations("pcbnfrsc", True, 256)
+        dev_t(a)
+    assert T.define_transformations("pcbnfrsc", False, 256).device_recipe is None          # evaluation: no augmentation
+    with pytest.raises(ValueError):
+        T.define_transformations("wcfrs", True, 256)                                       # not a recipe the reference defines either
     # reference raw tile format (datasets.py:452-466): "dtype w h c\\n" + bytes
     os.makedirs(tmp_path / "slideA"); os.makedirs(tmp_path / "slideB")
     for s, n in (("slideA", 3), ("slideB", 2)):

@@ -521,3 +521,53 @@ def test_crop_resize(dev):
         assert np.array_equal(got, ref), (out, int((got != ref).sum()), int(np.abs(got.astype(int) - ref.astype(int)).max()))
     with pytest.raises(L().GipvitError, match="multiple of 4"):
         ops().crop_resize(t_dev, b_dev, 98)
+
+
+@pytest.mark.parametrize("recipe", ["flip", "rvf", "cbnfrsc", "pcbnfrs", "cbnfr", "bnfrsc", "frs", "aug_receptornet"])
+def test_augment_byte_exact(dev, recipe):
+    """gv_augment against oracle/augment_oracle.py on the same draws: byte-identical tiles for every recipe of
+    transformations.py:131-197 (colour jitter in a random order, noise, flips / rotations, zoom, cutout)."""
+    import numpy as np
+    from gipvit import augment as A
+    from oracle import augment_oracle as ao
+    n, size = 6, 64
+    rng = np.random.default_rng(3)
+    tiles = rng.integers(0, 256, (n, size, size, 3), dtype=np.uint8)
+    tiles[0] = 200; tiles[1, :, :, :] = tiles[1, :, :, :1]               # a flat tile and a grey tile (hue / saturation corner cases)
+    aug = A.TileAugmenter(recipe, size, color_param=0.15, seed=5)
+    ps = [aug.sample_one() for _ in range(n)]
+    out, fill = aug.apply(torch.from_numpy(tiles).to(dev), params=ps)
+    torch.cuda.synchronize()
+    z = A.normal_table().numpy()
+    for i, p in enumerate(ps):
+        ref = ao.augment_tile(tiles[i], p, z)
+        got = out[i].cpu().numpy()
+        assert np.array_equal(got, ref), (recipe, i, int((got != ref).sum()), p)
+    assert (fill is not None) == any(p["fill"] for p in ps)
+
+
+def test_augment_blur_and_fill(dev):
+    """the 3x3 Gaussian blur with a real kernel (the recipes' sigma <= 0.1 makes it the identity) and the normalised fill
+    boxes gv_patchify applies (Cutout after Normalize, MeanPixelRegularization)."""
+    import numpy as np
+    from gipvit import augment as A
+    from oracle import augment_oracle as ao, vit_oracle as vo
+    rng = np.random.default_rng(4)
+    tiles = rng.integers(0, 256, (3, 64, 64, 3), dtype=np.uint8)
+    aug = A.TileAugmenter("cbnfr", 64, seed=1)
+    ps = []
+    for sigma in (0.8, 2.0, 0.35):
+        p = aug.sample_one(); p["blur"] = A.blur_weights(sigma); ps.append(p)
+    out, _ = aug.apply(torch.from_numpy(tiles).to(dev), params=ps)
+    z = A.normal_table().numpy()
+    for i, p in enumerate(ps):
+        assert np.array_equal(out[i].cpu().numpy(), ao.augment_tile(tiles[i], p, z)), i
+    # fill boxes in patchify: box -> the given normalised value, elsewhere (u8 / 255 - mean) / std
+    t = torch.from_numpy(tiles[:2]).to(dev)
+    fill = torch.tensor([[10, 40, 5, 33, 0.0, 0.0, 0.0, 1.0], [0, 64, 0, 64, 0.25, -0.5, 1.5, 1.0]], dtype=f32, device=dev)
+    got = ops().patchify(t, [(0, 0)], 64, vo.MEAN_RON, vo.STD_RON, fill=fill).float().cpu().view(2, 4, 4, 3, 16, 16)
+    ref = vo.normalize_window(torch.from_numpy(tiles[:2]), (0, 0, 64))                      # [2, 3, 64, 64]
+    ref[0, :, 10:40, 5:33] = 0.0
+    ref[1] = torch.tensor([0.25, -0.5, 1.5]).view(3, 1, 1)
+    ref_p = ref.view(2, 3, 4, 16, 4, 16).permute(0, 2, 4, 1, 3, 5)                          # [img, prow, pcol, c, py, px]
+    close(got, ref_p, 8e-3, 8e-3, "patchify fill")

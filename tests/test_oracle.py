@@ -231,3 +231,95 @@ def test_golden_dino_curve_fixture_reproduces():
     peak = 5e-4 * 8 / 256
     assert abs(dino_curve_schedule(24)["lr"] - (1e-6 + (peak - 1e-6) * 24 / 25)) < 1e-12                     # end of the linear warm-up
     assert abs(dino_curve_schedule(25)["lr"] - (1e-6 + 0.5 * (peak - 1e-6) * (1 + math.cos(math.pi / 4)))) < 1e-12   # timm cosine: t / epochs
+
+
+# --------------------------------------------------------------------------- augmentation oracle vs PIL
+def test_augment_oracle_colour_ops_match_pil():
+    """oracle/augment_oracle.py restates the PIL operations torchvision's ColorJitter runs on PIL images
+    (transformations.py:143-176): brightness / contrast / saturation byte-exact, HSV -> RGB exact over a dense grid,
+    RGB -> HSV exact on S and V and on the H byte for > 99.5 % of the colours (+-1 otherwise)."""
+    from PIL import Image, ImageEnhance
+    from oracle import augment_oracle as ao
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (96, 96, 3), dtype=np.uint8)
+    im = Image.fromarray(img)
+    for f in (0.85, 1.0, 1.15, 0.3, 1.7):
+        assert np.array_equal(ao.color_op(img, 0, {"bf": f}), np.asarray(ImageEnhance.Brightness(im).enhance(f)))
+        assert np.array_equal(ao.color_op(img, 1, {"cf": f}), np.asarray(ImageEnhance.Contrast(im).enhance(f)))
+        assert np.array_equal(ao.color_op(img, 2, {"sf": f}), np.asarray(ImageEnhance.Color(im).enhance(f)))
+    grid = np.stack(np.meshgrid(np.arange(0, 256, 3), np.arange(256), np.arange(0, 256, 2), indexing="ij"), -1).reshape(-1, 256, 3).astype(np.uint8)
+    assert np.array_equal(ao.hsv_to_rgb(grid), np.asarray(Image.fromarray(grid, mode="HSV").convert("RGB")))
+    hsv_pil = np.asarray(Image.fromarray(grid).convert("HSV"))
+    mine = ao.rgb_to_hsv(grid)
+    assert np.array_equal(mine[..., 1:], hsv_pil[..., 1:])
+    dh = np.abs(mine[..., 0].astype(int) - hsv_pil[..., 0].astype(int))
+    dh = np.minimum(dh, 256 - dh)
+    assert dh.max() <= 1 and (dh == 0).mean() > 0.995, (dh.max(), (dh == 0).mean())
+    # torchvision's adjust_hue on a PIL image: +shift on the H byte with wrap-around
+    for shift in (0, 10, 231):
+        h, s_, v = im.convert("HSV").split()
+        hh = (np.asarray(h).astype(np.int64) + shift) & 255
+        ref = np.asarray(Image.merge("HSV", (Image.fromarray(hh.astype(np.uint8), "L"), s_, v)).convert("RGB"))
+        got = ao.color_op(img, 3, {"hue": shift})
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert (d.max(-1) == 0).mean() > 0.99 and d.max() <= 6, ((d.max(-1) == 0).mean(), d.max())
+
+
+def test_augment_oracle_geometry_and_host_sampler():
+    """NEAREST zoom == PIL's affine transform (torchvision RandomAffine(degrees=0, scale) on PIL images); the dihedral
+    composition and the blur weights of the host sampler; recipes draw what the reference's Compose would."""
+    from PIL import Image
+    from oracle import augment_oracle as ao
+    from gipvit import augment as A
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    im = Image.fromarray(img)
+    for s in (1.0, 1.1234, 1.2, 1.19999, 1.05):
+        a = 1.0 / s
+        m = [a, 0.0, a * -128.0 + 128.0, 0.0, a, a * -128.0 + 128.0]
+        ref = np.asarray(im.transform((256, 256), Image.AFFINE, m, Image.NEAREST))
+        got = ao.zoom(img, *ao.zoom_fixed(s, 256))
+        assert (got == ref).all(-1).mean() > 0.95, s                      # identical except where the float matrix sits on a pixel edge
+        assert A.zoom_fixed(s, 256) == ao.zoom_fixed(s, 256)
+    assert np.array_equal(ao.zoom(img, *ao.zoom_fixed(1.0, 256)), img)
+    # dihedral composition: every sequence of flips / rotations is reproduced by the 3-bit element
+    small = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    for seq in ([], ["v"], ["h"], ["r1"], ["r2"], ["r3"], ["v", "r1"], ["r1", "v"], ["h", "r3"], ["v", "h"], ["r2", "v"], ["v", "r3", "h"]):
+        code = A.compose_d4(seq)
+        ys, xs = np.mgrid[0:8, 0:8]
+        u, v = (xs, ys) if code & 1 else (ys, xs)
+        u = 7 - u if code & 2 else u
+        v = 7 - v if code & 4 else v
+        assert np.array_equal(small[u, v], ao.augment_tile(small, {"geo": seq}, None)), seq
+    # blur weights = torchvision's _get_gaussian_kernel1d(3, sigma) (float32)
+    for sigma in (0.05, 0.5, 1.0):
+        x = torch.linspace(-1, 1, 3)
+        k = torch.exp(-0.5 * (x / sigma) ** 2); k = k / k.sum()
+        kc, ks = A.blur_weights(sigma)
+        assert abs(kc - float(k[1])) < 1e-7 and abs(ks - float(k[0])) < 1e-7
+    assert A.blur_weights(0.1)[1] < 1e-20                                    # the recipes' sigma <= 0.1: the blur is the identity
+    z = A.normal_table().numpy()
+    assert z.shape == (1024,) and abs(z.mean()) < 1e-6 and abs(z.std() - 1.0) < 5e-3 and np.all(np.diff(z) > 0)
+    aug = A.TileAugmenter("pcbnfrsc", 256, color_param=0.1, seed=0)
+    ps = [aug.sample_one() for _ in range(200)]
+    assert all(sorted(p["order"]) == [0, 1, 2, 3] and 0.9 <= p["bf"] <= 1.1 and 0.8 <= p["cf"] <= 1.2 and 0 <= p["sigma"] <= 0.05 for p in ps)
+    assert all(p["blur"] is None and p["fill"][4:] == (0.0, 0.0, 0.0) and p["fill"][1] - p["fill"][0] <= 100 for p in ps)
+    assert 0.3 < np.mean(["v" in p["geo"] for p in ps]) < 0.7 and {g for p in ps for g in p["geo"] if g[0] == "r"} == {"r0", "r1", "r2", "r3"}
+    assert all(65536 / 1.2 - 1 <= p["zoom"][0] <= 65536 for p in ps)
+    rp = A.TileAugmenter("aug_receptornet", 256, seed=1)
+    qs = [rp.sample_one() for _ in range(200)]
+    assert 0.6 < np.mean([q["fill"] is not None for q in qs]) < 0.9 and all("cut" in q for q in qs) and all(not q.get("zoom") for q in qs)
+    assert A.TileAugmenter("rvf", 64, seed=0).sample_one().keys() >= {"geo", "fill"}
+    packed = A.TileAugmenter.pack(ps[:3])
+    assert packed.dtype == np.uint8 and packed.size == 3 * 88
+    # the vectorised path the training loop uses packs exactly the records of the per-tile (oracle-format) draws
+    for rec in A.RECIPES:
+        au = A.TileAugmenter(rec, 256, 0.15, seed=3)
+        cols = au.sample_batch(32)
+        pk, fill = au.pack_batch(cols)
+        dicts = au.to_dicts(cols)
+        assert np.array_equal(pk, A.TileAugmenter.pack(dicts)), rec
+        assert (fill is not None) == any(d["fill"] for d in dicts)
+        if fill is not None:
+            for i, d in enumerate(dicts):
+                assert fill[i, 7] == (1.0 if d["fill"] else 0.0) and (not d["fill"] or np.allclose(fill[i, :7], d["fill"]))

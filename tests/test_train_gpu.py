@@ -107,6 +107,13 @@ def test_tiles_dataset_through_pinned_prefetcher(dev, tmp_path):
     assert rc == 0
     rows = list(csv.DictReader(open(tmp_path / "t" / "summary.csv")))
     assert len(rows) == 2 and all(np.isfinite(float(r["eval_loss"])) for r in rows)
+    # a named reference recipe (colour jitter, noise, flips / rotations, zoom, cutout after Normalize): augmented on the device
+    rc = train.main(["--model", "vit_tiny_patch16_224", "--dataset", f"tiles:{root}", "--num-classes", "2", "--img-size", "64", "--tile-size", "64",
+                     "-b", "4", "--epochs", "1", "--opt", "adamw", "--lr", "1e-4", "--warmup-epochs", "0", "--output", str(tmp_path), "--experiment", "aug",
+                     "--n_patches_train", "4", "--test_fold", "2", "--transform_type", "pcbnfrsc", "--c_param", "0.2", "--no-validate", "--log-interval", "1"])
+    assert rc == 0
+    r = list(csv.DictReader(open(tmp_path / "aug" / "summary.csv")))
+    assert len(r) == 1 and 0.3 < float(r[0]["train_loss"]) < 1.2
 
 
 def test_train_dino_checkpoint_and_resume(dev, tmp_path):

@@ -214,6 +214,12 @@ def main(argv=None):
     # ---- data (batch dict contract of the reference: 'Data', 'Target'; inference: Infer_Dataset's dict)
     synthetic = args.dataset in ("", "synthetic")
     transform = T.define_transformations(args.transform_type if not synthetic else "none", True, tile, args.c_param, "Ron")
+    # the named recipes run on the DEVICE once the tiles are in HBM (gv_augment); the reader threads then deliver raw tiles
+    augmenter = None
+    if getattr(transform, "device_recipe", None):
+        from gipvit.augment import TileAugmenter
+        augmenter = TileAugmenter(transform.device_recipe, tile, transform.color_param, mean, std, seed=args.seed + 31 * rank, device=dev)
+        transform = None
     inf_loader = None
     if synthetic:
         source = D.SyntheticTiles(B, tile, args.batches_per_epoch, args.num_classes or 2, seed=args.seed + rank)
@@ -335,7 +341,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     torch.cuda.set_stream(torch.cuda.Stream(dev, priority=-1))
     # tiles reach HBM one batch ahead of the step: pinned staging + a copy stream (replaces pin_memory workers, train.py:732)
-    loader = D.DevicePrefetcher(source, dev, (B, tile, tile, 3))
+    loader = D.DevicePrefetcher(source, dev, (B, tile, tile, 3), augmenter)
     cur_lr = lr
     # ---- epoch loop (train.py:905-977) / step loop (988-1143)
     for epoch in range(start_epoch, args.epochs):
@@ -347,6 +353,9 @@ def main(argv=None):
             eng.train_last_layer = epoch >= args.freeze_last_layer
         for batch_idx, mb in (enumerate(loader) if not args.extract_features else ()):      # train.py:906
             data, target = mb["Data"], mb["Target"]
+            fill = None
+            if augmenter is not None:      # the draws came with the batch (pinned staging); the pixel work is one launch here
+                data, fill = augmenter.run(data, mb["AugParams"]), mb["Fill"]
             data_time.update(time.time() - end)
             cur_lr = schedule.at(epoch, batch_idx)
             if args.dino:
@@ -354,9 +363,9 @@ def main(argv=None):
                 sch = dict(lr=cur_lr, wd=S.cosine_between(args.weight_decay, args.weight_decay_end, it, total_updates),
                            momentum_teacher=S.cosine_between(args.momentum_teacher, 1.0, it, total_updates),
                            teacher_temp=teacher_temp_at(args, epoch))
-                loss_t = eng.step(data, boxes=sampler.sample(dev) if sampler is not None else None, **sch)
+                loss_t = eng.step(data, boxes=sampler.sample(dev) if sampler is not None else None, fill=fill if sampler is None else None, **sch)
             else:
-                loss_t = eng.step(data, target, lr=cur_lr)
+                loss_t = eng.step(data, target, lr=cur_lr, fill=fill)
                 probs.append(eng.prob[:, 1].clone() if eng.C > 1 else eng.prob[:, 0].clone()); targets.append(target.view(-1).clone())
             torch.cuda.synchronize()                  # train.py:1083
             batch_time.update(time.time() - end)
