@@ -30,26 +30,29 @@ namespace {
 using namespace gvgemm;
 
 constexpr int PN = 384;              // output columns = the model width this kernel is built for (ViT-S)
-constexpr int PBK = 64;
-constexpr int PNW = 8;               // waves per workgroup
-constexpr int W_BLOCK = 128 * PBK * 2;      // one 128-column block of the weight stage (16 KB)
-constexpr int W_BYTES = 3 * W_BLOCK;
 constexpr int IMG_STRIDE = PN + 4;          // f32 image row stride (+4: conflict-free transposed writes)
 
-template <int FM>
+// Geometry: NW = 8 waves, each 3 column fragments x FM row fragments, BK = 64, ONE workgroup per CU (ring 2 x (A + 48 KB)).
+// (A 4-wave, BK = 32 variant with two workgroups per CU -- one workgroup's HBM-bound epilogue under the other's k-loop -- is
+// expressible with the same template and was measured: 103 vs 87 us on the K = 1536 forward; not instantiated.)
+template <int FM, int NW_, int BK_>
 struct PC {
+    static constexpr int NW = NW_, BK = BK_, KS = BK / 32, NF = 24 / NW;      // waves, k depth per stage, MFMA k-steps, column fragments per wave
     static constexpr int BM = FM * 16;
-    static constexpr int A_PPW = (FM * 2 + 7) / 8;          // 1-KB pieces (8 rows x 128 B) per wave
-    static constexpr int A_ROWS = A_PPW * 8 * 8;            // staged rows (>= BM; surplus rows are clamped duplicates)
-    static constexpr int A_BYTES = A_ROWS * 128;
-    static constexpr int STAGE = A_BYTES + W_BYTES;
+    static constexpr int RPP = 1024 / (BK * 2);             // rows per 1-KB piece of the A image
+    static constexpr int A_PPW = (FM * 16 + RPP * NW - 1) / (RPP * NW);      // pieces per wave
+    static constexpr int A_ROWS = A_PPW * RPP * NW;         // staged rows (>= BM; surplus rows are the next rows, clamped at M)
+    static constexpr int A_BYTES = A_ROWS * BK * 2;
+    static constexpr int W_BLOCK = 128 * BK * 2;            // one 128-column block of the weight stage
+    static constexpr int STAGE = A_BYTES + 3 * W_BLOCK;
     static constexpr int LDS = 2 * STAGE;
+    static constexpr int WG_PER_CU = NW == 8 ? 1 : 2;
     static constexpr int IB_FIT = LDS / (IMG_STRIDE * 4) / 16;
     // 16-row blocks per epilogue pass: bounded by the LDS image and by the registers that hold a pass's prefetched
     // global rows (forward: the residual row, 6 f32 per lane and row; backward: x and g rows, 12)
     static constexpr int ib(int want) { return want < (IB_FIT < FM ? IB_FIT : FM) ? want : (IB_FIT < FM ? IB_FIT : FM); }
-    static_assert(IB_FIT >= 1 && LDS <= 160 * 1024, "LDS budget");
-    static_assert(PNW * 3 * PN * 4 <= LDS, "column-sum reduction scratch must fit the ring");
+    static_assert(IB_FIT >= 1 && LDS * WG_PER_CU <= 160 * 1024, "LDS budget");
+    static_assert(NW * 3 * PN * 4 <= LDS, "column-sum reduction scratch must fit the ring");
 };
 
 // k-loop variants measured and dropped (round 2, M = 44 160, K = 1536, fused forward; tools/panel_probe.py gives 88 us for
@@ -72,9 +75,10 @@ struct PanelP {
 
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 
-template <int FM, bool TB, int MODE>
-__global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
-    using C = PC<FM>;
+template <int FM, int NW, int BK, bool TB, int MODE>
+__global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
+    using C = PC<FM, NW, BK>;
+    constexpr int NF = C::NF;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GV_LDS char* smem = (GV_LDS char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -83,25 +87,25 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
     const int m0 = blockIdx.x * C::BM;
     const int M = p.M;
 
-    // acc[i][j][r]: row m0 + 16 i + (lane & 15), column 16 (8 j + wave) + 4 (lane >> 4) + r
-    f32x4 acc[FM][3];
+    // acc[i][j][r]: row m0 + 16 i + (lane & 15), column 16 (NW j + wave) + 4 (lane >> 4) + r
+    f32x4 acc[FM][NF];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    TileSrc<false, C::A_ROWS, PBK, PNW> srcA;
-    TileSrc<TB, 128, PBK, PNW> srcW[3];
+    TileSrc<false, C::A_ROWS, BK, NW> srcA;
+    TileSrc<TB, 128, BK, NW> srcW[3];
     srcA.setup(p.A, p.lda, m0, M, wave, lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, PN, wave, lane);
-    const int nt = p.K / PBK;
+    const int nt = p.K / BK;
     auto issue = [&](int t) {
         GV_LDS char* st = smem + (t & 1) * C::STAGE;
-        const int k0 = t * PBK;
+        const int k0 = t * BK;
         srcA.issue(p.lda, k0, p.K, st, wave);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) srcW[j].issue(p.ldw, k0, p.K, st + C::A_BYTES + j * W_BLOCK, wave);
+        for (int j = 0; j < 3; ++j) srcW[j].issue(p.ldw, k0, p.K, st + C::A_BYTES + j * C::W_BLOCK, wave);
     };
     issue(0);
     for (int t = 0; t < nt; ++t) {
@@ -110,16 +114,19 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
         if (t + 1 < nt) issue(t + 1);
         GV_LDS char* cur = smem + (t & 1) * C::STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fw[3], fa[FM];
+        for (int ks = 0; ks < C::KS; ++ks) {
+            bf16x8 fw[NF], fa[FM];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) fw[j] = read_frag<TB, 128, PBK>(cur + C::A_BYTES + j * W_BLOCK, wave, ks, lane);
+            for (int j = 0; j < NF; ++j) {          // fragment f = NW j + wave lives in 128-column block f / 8 at local index f % 8
+                const int f = NW * j + wave;
+                fw[j] = read_frag<TB, 128, BK>(cur + C::A_BYTES + (f >> 3) * C::W_BLOCK, f & 7, ks, lane);
+            }
 #pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = read_frag<false, C::A_ROWS, PBK>(cur, i, ks, lane);
+            for (int i = 0; i < FM; ++i) fa[i] = read_frag<false, C::A_ROWS, BK>(cur, i, ks, lane);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
         }
     }
     // ---- epilogue.  The accumulators pass through an LDS image so that the row phase works on whole rows, ONE WAVE PER
@@ -127,14 +134,14 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
     // of the LayerNorm stay inside a wave.  The global rows a pass needs (forward: the residual; backward: x and g, mean,
     // rstd) are all requested BEFORE the pass's image barrier, so their HBM latency overlaps the image traffic and the
     // other rows' arithmetic instead of being paid once per row.
-    constexpr int IB = C::ib(MODE == MODE_FWD ? 5 : 3);
-    constexpr int RPW = 2 * IB;                                   // rows per wave and pass
+    constexpr int IB = C::ib(NW == 8 ? (MODE == MODE_FWD ? 5 : 3) : (MODE == MODE_FWD ? 2 : 1));
+    constexpr int RPW = 16 * IB / NW;                             // rows per wave and pass
     GV_LDS float* img = (GV_LDS float*)smem;
-    f32x4 bias4[3];
+    f32x4 bias4[NF];
     if constexpr (MODE == MODE_FWD) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            bias4[j] = p.bias ? *(const f32x4*)(p.bias + 16 * (8 * j + wave) + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j)
+            bias4[j] = p.bias ? *(const f32x4*)(p.bias + 16 * (NW * j + wave) + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // per-lane column constants of the row phase: lane owns columns (c * 64 + lane) * 2 + {0, 1}, c = 0..2
     float gm[3][2], bt[3][2];
@@ -159,8 +166,8 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
         float pre_mean[MODE == MODE_BWD ? RPW : 1], pre_rstd[MODE == MODE_BWD ? RPW : 1];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            if (rr < 2 * ni) {
-                int m = m0 + i0 * 16 + wave + 8 * rr;
+            if (rr < 16 * ni / NW) {
+                int m = m0 + i0 * 16 + wave + NW * rr;
                 m = m < M ? m : M - 1;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -181,10 +188,10 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
         for (int ii = 0; ii < IB; ++ii) {
             if (ii < ni) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < NF; ++j) {
                     f32x4 v = acc[i0 + ii][j];
                     if constexpr (MODE == MODE_FWD) v += bias4[j];
-                    *(GV_LDS f32x4*)(img + (ii * 16 + li16) * IMG_STRIDE + 16 * (8 * j + wave) + gq * 4) = v;
+                    *(GV_LDS f32x4*)(img + (ii * 16 + li16) * IMG_STRIDE + 16 * (NW * j + wave) + gq * 4) = v;
                 }
             }
         }
@@ -192,8 +199,8 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
         // ---- one wave per row
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            if (rr < 2 * ni) {
-                const int r = wave + 8 * rr;
+            if (rr < 16 * ni / NW) {
+                const int r = wave + NW * rr;
                 const int m = m0 + i0 * 16 + r;
                 if (m < M) {                                      // wave-uniform
                     float v[3][2];
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
 
     if constexpr (MODE == MODE_BWD) {
         // column sums over this workgroup's rows -> partials[blockIdx][3][384] (gv_ln_finalize folds them)
-        GV_LDS float* red = (GV_LDS float*)smem;                  // [8 waves][3][384]
+        GV_LDS float* red = (GV_LDS float*)smem;                  // [NW waves][3][384]
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -277,40 +284,40 @@ __global__ __launch_bounds__(512, 2) void panel_kernel(const PanelP p) {
             }
         __syncthreads();
         float* outp = p.partials + (long)blockIdx.x * 3 * PN;
-        for (int idx = tid; idx < 3 * PN; idx += 512) {
+        for (int idx = tid; idx < 3 * PN; idx += NW * 64) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < PNW; ++w) s += red[w * 3 * PN + idx];
+            for (int w = 0; w < NW; ++w) s += red[w * 3 * PN + idx];
             outp[idx] = s;
         }
     }
 }
 
-// smallest supported FM that covers M rows in as few full rounds of 256 workgroups as possible
-constexpr int FM_SET[] = {4, 7, 9, 11, 12};
+// rows per workgroup for M rows: the smallest supported FM that covers M in as few full rounds of 256 workgroups as possible
+constexpr int FM_SET8[] = {4, 7, 9, 11, 12};
 int pick_fm(int M) {
     const int m16 = (M + 15) / 16;
     const int rounds = (m16 + 256 * 12 - 1) / (256 * 12);
     const int need = (m16 + 256 * rounds - 1) / (256 * rounds);
-    for (int fm : FM_SET) if (fm >= need) return fm;
+    for (int fm : FM_SET8) if (fm >= need) return fm;
     return 12;
 }
 
-template <int FM, bool TB, int MODE>
+template <int FM, int NW, int BK, bool TB, int MODE>
 int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
-    auto kern = panel_kernel<FM, TB, MODE>;
-    constexpr int LDS_BYTES = PC<FM>::LDS;
+    auto kern = panel_kernel<FM, NW, BK, TB, MODE>;
+    using C = PC<FM, NW, BK>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) { gv_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     static char kname[96] = "";
-    if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %s, %d>", FM, TB ? "true" : "false", MODE);
-    const int grid = (p.M + PC<FM>::BM - 1) / PC<FM>::BM;
+    if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d>", FM, NW, BK, TB ? "true" : "false", MODE);
+    const int grid = (p.M + C::BM - 1) / C::BM;
     const int th = gvtime::enabled() ? gvtime::begin(kname, 2.0 * p.M * PN * p.K, s) : -1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), C::LDS, s, p);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK(name);
     return GV_OK;
@@ -319,11 +326,11 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
 template <bool TB, int MODE>
 int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
     switch (pick_fm(p.M)) {
-        case 4: return launch_panel<4, TB, MODE>(p, s, name);
-        case 7: return launch_panel<7, TB, MODE>(p, s, name);
-        case 9: return launch_panel<9, TB, MODE>(p, s, name);
-        case 11: return launch_panel<11, TB, MODE>(p, s, name);
-        default: return launch_panel<12, TB, MODE>(p, s, name);
+        case 4: return launch_panel<4, 8, 64, TB, MODE>(p, s, name);
+        case 7: return launch_panel<7, 8, 64, TB, MODE>(p, s, name);
+        case 9: return launch_panel<9, 8, 64, TB, MODE>(p, s, name);
+        case 11: return launch_panel<11, 8, 64, TB, MODE>(p, s, name);
+        default: return launch_panel<12, 8, 64, TB, MODE>(p, s, name);
     }
 }
 
@@ -337,7 +344,7 @@ extern "C" int gv_linear_ln_blocks(int32_t M) {
 extern "C" int gv_linear_ln_fwd(const gv_linear_ln_fwd_args* a, void* stream) {
     GV_REQUIRE(a && a->A && a->W && a->out, GV_E_NULL, "gv_linear_ln_fwd: null operand");
     GV_REQUIRE(a->N == PN, GV_E_UNSUPPORTED, "gv_linear_ln_fwd: built for N = %d output columns (ViT-S), got %d", PN, a->N);
-    GV_REQUIRE(a->M > 0 && a->K > 0 && a->K % PBK == 0, GV_E_SHAPE, "gv_linear_ln_fwd: need M > 0 and K %% 64 == 0 (got M=%d K=%d)", a->M, a->K);
+    GV_REQUIRE(a->M > 0 && a->K > 0 && a->K % 64 == 0, GV_E_SHAPE, "gv_linear_ln_fwd: need M > 0 and K %% 64 == 0 (got M=%d K=%d)", a->M, a->K);
     GV_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldo % 2 == 0 && a->ldr % 4 == 0, GV_E_ALIGN, "gv_linear_ln_fwd: leading dimensions misaligned");
     GV_REQUIRE(gv_aligned(a->A, 16) && gv_aligned(a->W, 16) && gv_aligned(a->out, 16), GV_E_ALIGN, "gv_linear_ln_fwd: A/W/out must be 16-byte aligned");
     if (a->bias) GV_REQUIRE(gv_aligned(a->bias, 16), GV_E_ALIGN, "gv_linear_ln_fwd: bias misaligned");
@@ -353,7 +360,7 @@ extern "C" int gv_linear_ln_fwd(const gv_linear_ln_fwd_args* a, void* stream) {
 extern "C" int gv_linear_ln_bwd(const gv_linear_ln_bwd_args* a, void* stream) {
     GV_REQUIRE(a && a->A && a->W && a->x && a->mean && a->rstd && a->gamma && a->g && a->partials, GV_E_NULL, "gv_linear_ln_bwd: null operand");
     GV_REQUIRE(a->N == PN, GV_E_UNSUPPORTED, "gv_linear_ln_bwd: built for N = %d output columns (ViT-S), got %d", PN, a->N);
-    GV_REQUIRE(a->M > 0 && a->K > 0 && a->K % PBK == 0, GV_E_SHAPE, "gv_linear_ln_bwd: need M > 0 and K %% 64 == 0 (got M=%d K=%d)", a->M, a->K);
+    GV_REQUIRE(a->M > 0 && a->K > 0 && a->K % 64 == 0, GV_E_SHAPE, "gv_linear_ln_bwd: need M > 0 and K %% 64 == 0 (got M=%d K=%d)", a->M, a->K);
     GV_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldx % 2 == 0 && a->ldg % 2 == 0 && a->ldgb % 2 == 0, GV_E_ALIGN,
                "gv_linear_ln_bwd: leading dimensions misaligned");
     GV_REQUIRE(gv_aligned(a->A, 16) && gv_aligned(a->W, 16) && gv_aligned(a->x, 8) && gv_aligned(a->g, 8), GV_E_ALIGN, "gv_linear_ln_bwd: misaligned pointer");
