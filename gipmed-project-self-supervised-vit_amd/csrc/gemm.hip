@@ -42,7 +42,10 @@
 #define GV_GEMM_NSTAGE 2
 #endif
 #include "gemm_core.h"
+#include "gemm_dw8.h"
 #include "timing.h"
+#include <type_traits>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include <string.h>
@@ -150,9 +153,78 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const ReduceGr
 
 constexpr long WORKSPACE_BYTES = 64L << 20;
 
+// dW over many token rows on the 8-wave ping-pong kernel (gemm_dw8.h).  Returns -1 when the shape is not one of its own
+// (the caller then takes the 128x128 split-K path), else the launch status.
+template <bool SWAP>
+int launch_dw8(const Dw8P& q, float* C, long ldc, int M, int N, hipStream_t s) {
+    auto kern = dw8_kernel<SWAP>;
+#ifdef GV_DW8_LAB     // tuning lab: ablation variants by environment (tools/dw8_lab.sh)
+    {
+        const char* ev = getenv("GIPVIT_DW8_VAR");
+        const int var = ev ? atoi(ev) : 0;
+        switch (var) {
+            case 1: kern = dw8_kernel<SWAP, 1>; break; case 2: kern = dw8_kernel<SWAP, 2>; break; case 4: kern = dw8_kernel<SWAP, 4>; break;
+            case 8: kern = dw8_kernel<SWAP, 8>; break; case 16: kern = dw8_kernel<SWAP, 16>; break; case 24: kern = dw8_kernel<SWAP, 24>; break;
+            case 32: kern = dw8_kernel<SWAP, 32>; break; case 56: kern = dw8_kernel<SWAP, 56>; break;
+            default: break;
+        }
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DW8_LDS);
+    }
+#endif
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DW8_LDS);
+        if (e != hipSuccess) { gv_set_error("gemm(dw8): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    const int th = gvtime::enabled() ? gvtime::begin(SWAP ? "dw8_kernel<swapped>" : "dw8_kernel<normal>", 2.0 * M * N * q.K, s) : -1;
+    hipLaunchKernelGGL(kern, dim3(q.tiles_p * q.tiles_q * q.ksplit), dim3(512), DW8_LDS, s, q);
+    gvtime::end(th, s);
+    GV_LAUNCH_CHECK("gv_linear(dw8)");
+    const long MN4 = (long)M * N / 4;
+    long blocks = (MN4 + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)q.slab, C, MN4, q.ksplit, N / 4, ldc / 4);
+    GV_LAUNCH_CHECK("gv_linear(dw8 reduce)");
+    return GV_OK;
+}
+
+#ifdef GV_DW8_STAMPS
+unsigned long long* g_dw8_dbg = nullptr;
+#endif
+int try_dw8(const gv_linear_args* a, hipStream_t s) {
+    if (!(a->trans_a && a->trans_b && a->c_is_f32 && a->epilogue == GV_EPI_ACCUM && a->workspace && gv_aligned(a->workspace, 16))) return -1;
+    if (a->alpha != 0.f && a->alpha != 1.f) return -1;
+    if (a->K < 2048) return -1;
+    const bool normal = a->M % 128 == 0 && a->N % 384 == 0;
+    const bool swapped = !normal && a->N % 128 == 0 && a->M % 384 == 0 && (!a->colsum_a || a->N / 128 >= 12);
+    if (!normal && !swapped) return -1;
+    Dw8P q;
+    q.K = a->K; q.slab = (float*)a->workspace; q.colsum = a->colsum_a;
+#ifdef GV_DW8_STAMPS
+    { static unsigned long long* dbg = nullptr; if (!dbg) { (void)hipMalloc(&dbg, 256 * 8 * 8 * 8); } q.dbg = dbg; g_dw8_dbg = dbg; }
+#endif
+    if (normal) { q.P = (const bf16*)a->A; q.ldp = a->lda; q.Pn = a->M; q.Q = (const bf16*)a->B; q.ldq = a->ldb; q.Qn = a->N; }
+    else { q.P = (const bf16*)a->B; q.ldp = a->ldb; q.Pn = a->N; q.Q = (const bf16*)a->A; q.ldq = a->lda; q.Qn = a->M; }
+    q.tiles_p = q.Pn / 128; q.tiles_q = q.Qn / 384;
+    const int tiles = q.tiles_p * q.tiles_q;
+    if (tiles > 256) return -1;
+    // one workgroup per CU and never a second round: S = floor(256 / tiles) slices of at least four K-tiles
+    const int ktiles = (a->K + 63) / 64;
+    const int want = 256 / tiles, maxs = ktiles / 4 > 0 ? ktiles / 4 : 1;
+    int S = want < maxs ? want : maxs;
+    const int per = (ktiles + S - 1) / S;
+    S = (ktiles + per - 1) / per;
+    if ((long)S * a->M * a->N * 4 > a->workspace_bytes) return -1;
+    q.ksplit = S; q.k_per_split = per * 64;
+    return normal ? launch_dw8<false>(q, (float*)a->C, a->ldc, a->M, a->N, s) : launch_dw8<true>(q, (float*)a->C, a->ldc, a->M, a->N, s);
+}
+
 }  // namespace
 
 extern "C" int64_t gv_linear_workspace_bytes(void) { return WORKSPACE_BYTES; }
+#ifdef GV_DW8_STAMPS   // tuning-lab build only (tools/dw_bench.py)
+extern "C" int gv_dw8_dbg_read(unsigned long long* host) { if (!g_dw8_dbg) return -1; return (int)hipMemcpy(host, g_dw8_dbg, 256 * 8 * 8 * 8, hipMemcpyDeviceToHost); }
+#endif
 
 // ---- live per-kernel timing (timing.h; gv_linear_timing / gv_linear_timing_read of include/gipvit.h)
 namespace {
@@ -245,6 +317,10 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     if (e & GV_EPI_ACCUM) GV_REQUIRE(a->c_is_f32, GV_E_UNSUPPORTED, "gv_linear: ACCUM needs an f32 C");
     GV_REQUIRE(a->ldc % 4 == 0, GV_E_ALIGN, "gv_linear: ldc must be a multiple of 4");
 
+    {
+        const int rc = try_dw8(a, (hipStream_t)stream);
+        if (rc != -1) return rc;
+    }
     GemmP p;
     p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
@@ -333,6 +409,67 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
 extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream) {
     GV_REQUIRE(a && a->n >= 1 && a->n <= GV_DW_GROUP_MAX, GV_E_SHAPE, "gv_linear_dw_group: 1..%d problems", GV_DW_GROUP_MAX);
     GV_REQUIRE(a->K > 0 && a->workspace && gv_aligned(a->workspace, 16), GV_E_NULL, "gv_linear_dw_group: K > 0 and an aligned workspace are required");
+    hipStream_t s = (hipStream_t)stream;
+    // ---- ping-pong kernel (gemm_dw8.h) when every problem tiles into 128 x 384 pieces
+    {
+        bool ok8 = a->K >= 2048;
+        int tiles8 = 0;
+        for (int q = 0; q < a->n && ok8; ++q) {
+            const auto& pr = a->prob[q];
+            ok8 = pr.dY && pr.X && pr.dW && pr.M > 0 && pr.N > 0 && pr.M % 128 == 0 && pr.N % 384 == 0 && pr.ldy % 8 == 0 && pr.ldx % 8 == 0 && pr.ldw % 4 == 0 &&
+                  gv_aligned(pr.dY, 16) && gv_aligned(pr.X, 16) && gv_aligned(pr.dW, 16);
+            if (ok8) tiles8 += (pr.M / 128) * (pr.N / 384);
+        }
+        if (ok8 && tiles8 <= 256) {
+            const int ktiles = (a->K + 63) / 64;
+            const int want = 256 / tiles8, maxs = ktiles / 4 > 0 ? ktiles / 4 : 1;
+            int S = want < maxs ? want : maxs;
+            const int per = (ktiles + S - 1) / S;
+            S = (ktiles + per - 1) / per;
+            Dw8GroupP G8{};
+            G8.n = a->n;
+            long slab_floats = 0; int tb = 0; double flops = 0;
+            for (int q = 0; q < a->n; ++q) {
+                const auto& pr = a->prob[q];
+                Dw8P& d = G8.prob[q];
+                d.P = (const bf16*)pr.dY; d.ldp = pr.ldy; d.Pn = pr.M; d.Q = (const bf16*)pr.X; d.ldq = pr.ldx; d.Qn = pr.N;
+                d.K = a->K; d.tiles_p = pr.M / 128; d.tiles_q = pr.N / 384; d.ksplit = S; d.k_per_split = per * 64;
+                d.slab = a->workspace + slab_floats; d.colsum = pr.colsum_dy;
+#ifdef GV_DW8_STAMPS
+                d.dbg = nullptr;
+#endif
+                slab_floats += (long)S * pr.M * pr.N;
+                G8.tile_base[q] = tb; tb += d.tiles_p * d.tiles_q;
+                flops += 2.0 * pr.M * pr.N * a->K;
+            }
+            for (int q = a->n; q <= GV_DW_GROUP_MAX; ++q) G8.tile_base[q] = tb;
+            G8.total_tiles = tb;
+            if (slab_floats * 4 <= a->workspace_bytes) {
+                static bool attr8 = false;
+                if (!attr8) {
+                    hipError_t e = hipFuncSetAttribute((const void*)dw8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW8_LDS);
+                    if (e != hipSuccess) { gv_set_error("gv_linear_dw_group: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+                    attr8 = true;
+                }
+                const int th = gvtime::enabled() ? gvtime::begin("dw8_group_kernel", flops, s) : -1;
+                hipLaunchKernelGGL(dw8_group_kernel, dim3(tb * S), dim3(512), DW8_LDS, s, G8);
+                gvtime::end(th, s);
+                GV_LAUNCH_CHECK("gv_linear_dw_group(dw8)");
+                ReduceGroupP R{};
+                long max4 = 0;
+                for (int q = 0; q < a->n; ++q) {
+                    const auto& pr = a->prob[q];
+                    R.slab[q] = G8.prob[q].slab; R.C[q] = pr.dW; R.MN4[q] = (long)pr.M * pr.N / 4; R.N4[q] = pr.N / 4; R.ldc4[q] = pr.ldw / 4;
+                    if (R.MN4[q] > max4) max4 = R.MN4[q];
+                }
+                R.S = S;
+                long blocks = (max4 + 255) / 256; if (blocks > 1024) blocks = 1024;
+                hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)blocks, a->n), dim3(256), 0, s, R);
+                GV_LAUNCH_CHECK("gv_linear_dw_group(dw8 reduce)");
+                return GV_OK;
+            }
+        }
+    }
     GroupP G{};
     G.n = a->n;
     int tiles = 0;
@@ -370,7 +507,6 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
         slab_floats += (long)ksplit * p.M * p.N;
     }
     GV_REQUIRE(slab_floats * 4 <= a->workspace_bytes, GV_E_SHAPE, "gv_linear_dw_group: workspace too small (%ld bytes needed)", slab_floats * 4);
-    hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCfg::LDS);

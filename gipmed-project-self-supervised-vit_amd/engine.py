@@ -252,11 +252,10 @@ class VitRunner:
         # full-row Linear + LayerNorm kernels (csrc/panel.hip) exist for the ViT-S width; GIPVIT_FUSED_LN=0 keeps the
         # round-1 pair (128x128-tile GEMM + stand-alone LayerNorm pass) for A/B runs
         self.fused = self.D == 384 and os.environ.get("GIPVIT_FUSED_LN", "1") != "0"
-        # GIPVIT_GROUP_DW=1: the four weight-gradient products of a block as ONE split-K launch (gv_linear_dw_group).  Measured
-        # (gpurun_out/r2_dwexp.log): the grouped kernel is faster by itself (752 vs 586 TFLOP/s, 28 MB of slab instead of
-        # 4 x 32 MB) but the STEP is slower (16.0 vs 15.6 ms): its 200-us workgroups hold LDS that the main stream's
-        # one-per-CU full-row kernels wait for, while four short launches per block interleave with them.  Off by default.
-        self.group_dw = os.environ.get("GIPVIT_GROUP_DW", "0") == "1"
+        # the four weight-gradient products of a block as ONE split-K launch (gv_linear_dw_group): a quarter of the slab
+        # traffic and four times longer k-loops than four launches (ViT-S: 165 us per block at 950 TFLOP/s against
+        # 4 x (51 + 7) us).  GIPVIT_GROUP_DW=0 keeps one launch per product for A/B runs.
+        self.group_dw = os.environ.get("GIPVIT_GROUP_DW", "1") != "0"
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
         self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)

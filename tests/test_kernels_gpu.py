@@ -219,11 +219,12 @@ def test_linear_ln_bwd(dev, M, K, g_init):
     assert bool(torch.isnan(partials[nb:]).all())                   # nothing written beyond the reported block count
 
 
-def test_linear_dw_group_exact(dev):
+@pytest.mark.parametrize("T", [1500, 3000, 8192])
+def test_linear_dw_group_exact(dev, T):
     """gv_linear_dw_group: the four weight gradients of a block in one split-K launch == four dY^T X products (+ column sums),
-    bit exact on integer data; accumulates into dW."""
+    bit exact on integer data; accumulates into dW.  T < 2048 runs the 128x128-tile kernel, T >= 2048 the ping-pong kernel
+    (ragged last K-tile at 3000)."""
     o = ops()
-    T = 3000
     shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]
     probs, refs = [], []
     for q, (Mq, Nq) in enumerate(shapes):
