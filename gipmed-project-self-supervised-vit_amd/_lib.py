@@ -106,7 +106,7 @@ PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspac
 
 
 class gv_linear_timing_row(C.Structure):
-    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int32), ("seconds", C.c_double), ("flops", C.c_double)]
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int32), ("seconds", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_POS, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 LN_PARTIAL_BLOCKS = 1024

@@ -240,26 +240,33 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
         stage_rows(base + H * 64, ld, N, NP, P0 + IMG, wave, NW, lane);
         stage_rows((const bf16*)a.d_o + (long)img * N * ldo + h * 64, ldo, N, NP, P0 + 2 * IMG, wave, NW, lane);
     }
-    for (int u = threadIdx.x; u < PAIRS * NP; u += NW * 64) {
-        const int pr = u / NP, q = u - pr * NP;
-        int pair = blockIdx.x * PAIRS + pr;
+    // delta[q] = sum_d O[q][d] dO[q][d] and lse[q], one query per thread (NW * 64 >= PAIRS * NP for every NKT): the O row is
+    // fetched into registers now, the dO row is taken from the LDS image once it has landed -- dO makes ONE trip from HBM
+    static_assert(NW * 64 >= PAIRS * NP, "one (pair, query) per thread");
+    const int dq_pr = threadIdx.x / NP, dq_q = threadIdx.x - dq_pr * NP;
+    const bool dq_has = (int)threadIdx.x < PAIRS * NP, dq_live = dq_has && dq_q < N;
+    // (the 9-wave N <= 288 build has 168 registers per lane: there the row is multiplied against dO from global straight away)
+    constexpr bool DELTA_LDS = NKT < 18;
+    bf16x8 orow8[DELTA_LDS ? 8 : 1];
+    float lse_q = 0.f, delta_q = 0.f;
+    if (dq_live) {
+        int pair = blockIdx.x * PAIRS + dq_pr;
         pair = pair < n_pairs ? pair : n_pairs - 1;
         const int img = pair / H, h = pair - img * H;
-        GV_LDS float* dl = (GV_LDS float*)(smem + pr * PER_PAIR + 3 * IMG + DST);
-        float d = 0.f, l = 0.f;
-        if (q < N) {
-            const bf16* orow = (const bf16*)a.o + ((long)img * N + q) * ldo + h * 64;
-            const bf16* drow = (const bf16*)a.d_o + ((long)img * N + q) * ldo + h * 64;
+        const bf16* orow = (const bf16*)a.o + ((long)img * N + dq_q) * ldo + h * 64;
+        if constexpr (DELTA_LDS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) orow8[i] = *(const bf16x8*)(orow + i * 8);
+        } else {
+            const bf16* drow = (const bf16*)a.d_o + ((long)img * N + dq_q) * ldo + h * 64;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const bf16x8 x = *(const bf16x8*)(orow + i * 8), y = *(const bf16x8*)(drow + i * 8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) d += (float)x[j] * (float)y[j];
+                for (int j = 0; j < 8; ++j) delta_q += (float)x[j] * (float)y[j];
             }
-            l = a.lse[((long)img * H + h) * N + q];
         }
-        dl[q] = d;
-        dl[NP + q] = l;
+        lse_q = a.lse[((long)img * H + h) * N + dq_q];
     }
     const int lp = wave / NKB, kb = wave % NKB;        // local pair, this wave's 32-key block
     const int pair_raw = blockIdx.x * PAIRS + lp;
@@ -287,6 +294,24 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
         for (int ks = 0; ks < 2; ++ks) vf[kt][ks] = *(const bf16x8*)(vrow + ks * 32 + g * 8);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (dq_has) {
+        GV_LDS char* P0 = smem + dq_pr * PER_PAIR;
+        GV_LDS float* dl = (GV_LDS float*)(P0 + 3 * IMG + DST);
+        float d = delta_q;
+        if constexpr (DELTA_LDS) {
+            if (dq_live) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bf16x8 x = orow8[i], y = read_nat(P0 + 2 * IMG, dq_q, i);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += (float)x[j] * (float)y[j];
+                }
+            }
+        }
+        dl[dq_q] = d;
+        dl[NP + dq_q] = lse_q;
+    }
     __syncthreads();
 
     // this wave's K fragments (B operands: lane = key, 8 consecutive d)

@@ -90,7 +90,17 @@ int launch(const GemmP& p, hipStream_t s) {
     // measured (tools/gemm_lab): with K = 384..2048 one workgroup per item beats a persistent walk
     const int grid = items;
     (void)PERSISTENT_GRID;
-    const int th = gvtime::enabled() ? gvtime::begin(kernel_name<TA, TB, OutT, ATOMIC, EPI>(), 2.0 * p.M * p.N * p.K, s) : -1;
+    int th = -1;
+    if (gvtime::enabled()) {      // algorithmic bytes: operands once, output once, epilogue operands once
+        const int e = EPI >= 0 ? EPI : p.epi;
+        const double mn = (double)p.M * p.N;
+        double bytes = 2.0 * p.K * ((double)p.M + p.N) + mn * sizeof(OutT);
+        if (e & GV_EPI_ACCUM) bytes += mn * 4;
+        if (e & GV_EPI_RESID) bytes += mn * 4;
+        if (e & GV_EPI_DGELU) bytes += mn * 2;
+        if (e & GV_EPI_SAVE_PRE) bytes += mn * 2;
+        th = gvtime::begin(kernel_name<TA, TB, OutT, ATOMIC, EPI>(), 2.0 * p.M * p.N * p.K, bytes, s);
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), PCfg::LDS, s, p);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK("gv_linear");
@@ -177,7 +187,7 @@ int launch_dw8(const Dw8P& q, float* C, long ldc, int M, int N, hipStream_t s) {
         if (e != hipSuccess) { gv_set_error("gemm(dw8): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    const int th = gvtime::enabled() ? gvtime::begin(SWAP ? "dw8_kernel<swapped>" : "dw8_kernel<normal>", 2.0 * M * N * q.K, s) : -1;
+    const int th = gvtime::enabled() ? gvtime::begin(SWAP ? "dw8_kernel<swapped>" : "dw8_kernel<normal>", 2.0 * M * N * q.K, 2.0 * q.K * ((double)M + N) + 8.0 * M * N, s) : -1;
     hipLaunchKernelGGL(kern, dim3(q.tiles_p * q.tiles_q * q.ksplit), dim3(512), DW8_LDS, s, q);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK("gv_linear(dw8)");
@@ -228,7 +238,7 @@ extern "C" int gv_dw8_dbg_read(unsigned long long* host) { if (!g_dw8_dbg) retur
 
 // ---- live per-kernel timing (timing.h; gv_linear_timing / gv_linear_timing_read of include/gipvit.h)
 namespace {
-struct TimingRec { const char* name; hipEvent_t e0, e1; double flops; };
+struct TimingRec { const char* name; hipEvent_t e0, e1; double flops, bytes; };
 struct Timing {
     std::mutex mu;
     bool on = false;
@@ -245,11 +255,11 @@ Timing& timing() { static Timing t; return t; }
 }  // namespace
 
 bool gvtime::enabled() { return timing().on; }
-int gvtime::begin(const char* kernel_name, double flops, hipStream_t s) {
+int gvtime::begin(const char* kernel_name, double flops, double bytes, hipStream_t s) {
     Timing& tm = timing();
     std::lock_guard<std::mutex> lk(tm.mu);
     if (!tm.on) return -1;
-    TimingRec r{kernel_name, tm.get(), tm.get(), flops};
+    TimingRec r{kernel_name, tm.get(), tm.get(), flops, bytes};
     (void)hipEventRecord(r.e0, s);
     tm.recs.push_back(r);
     return (int)tm.recs.size() - 1;
@@ -291,7 +301,7 @@ extern "C" int gv_linear_timing_read(gv_linear_timing_row* rows, int max_rows) {
             strncpy(rows[n].name, r.name, sizeof(rows[n].name) - 1);
             ++n;
         }
-        rows[i].launches += 1; rows[i].seconds += ms * 1e-3; rows[i].flops += r.flops;
+        rows[i].launches += 1; rows[i].seconds += ms * 1e-3; rows[i].flops += r.flops; rows[i].bytes += r.bytes;
     }
     return n;
 }
@@ -318,7 +328,9 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     GV_REQUIRE(a->ldc % 4 == 0, GV_E_ALIGN, "gv_linear: ldc must be a multiple of 4");
 
     {
-        const int rc = try_dw8(a, (hipStream_t)stream);
+        int rc = try_dw8(a, (hipStream_t)stream);
+        if (rc != -1) return rc;
+        rc = gv_panel_wide(a, (hipStream_t)stream);
         if (rc != -1) return rc;
     }
     GemmP p;
@@ -428,7 +440,7 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
             S = (ktiles + per - 1) / per;
             Dw8GroupP G8{};
             G8.n = a->n;
-            long slab_floats = 0; int tb = 0; double flops = 0;
+            long slab_floats = 0; int tb = 0; double flops = 0, bytes = 0;
             for (int q = 0; q < a->n; ++q) {
                 const auto& pr = a->prob[q];
                 Dw8P& d = G8.prob[q];
@@ -440,7 +452,7 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
 #endif
                 slab_floats += (long)S * pr.M * pr.N;
                 G8.tile_base[q] = tb; tb += d.tiles_p * d.tiles_q;
-                flops += 2.0 * pr.M * pr.N * a->K;
+                flops += 2.0 * pr.M * pr.N * a->K; bytes += 2.0 * a->K * ((double)pr.M + pr.N) + 8.0 * pr.M * pr.N;
             }
             for (int q = a->n; q <= GV_DW_GROUP_MAX; ++q) G8.tile_base[q] = tb;
             G8.total_tiles = tb;
@@ -451,7 +463,7 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
                     if (e != hipSuccess) { gv_set_error("gv_linear_dw_group: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
                     attr8 = true;
                 }
-                const int th = gvtime::enabled() ? gvtime::begin("dw8_group_kernel", flops, s) : -1;
+                const int th = gvtime::enabled() ? gvtime::begin("dw8_group_kernel", flops, bytes, s) : -1;
                 hipLaunchKernelGGL(dw8_group_kernel, dim3(tb * S), dim3(512), DW8_LDS, s, G8);
                 gvtime::end(th, s);
                 GV_LAUNCH_CHECK("gv_linear_dw_group(dw8)");
@@ -513,9 +525,9 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
         if (e != hipSuccess) { gv_set_error("gv_linear_dw_group: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    double flops = 0;
-    for (int q = 0; q < a->n; ++q) flops += 2.0 * G.prob[q].M * G.prob[q].N * a->K;
-    const int th = gvtime::enabled() ? gvtime::begin("gemm_dw_group_kernel", flops, s) : -1;
+    double flops = 0, bytes = 0;
+    for (int q = 0; q < a->n; ++q) { flops += 2.0 * G.prob[q].M * G.prob[q].N * a->K; bytes += 2.0 * a->K * ((double)G.prob[q].M + G.prob[q].N) + 8.0 * G.prob[q].M * G.prob[q].N; }
+    const int th = gvtime::enabled() ? gvtime::begin("gemm_dw_group_kernel", flops, bytes, s) : -1;
     hipLaunchKernelGGL(gemm_dw_group_kernel, dim3(tiles * ksplit), dim3(PCfg::THREADS), PCfg::LDS, s, G);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK("gv_linear_dw_group");

@@ -51,6 +51,10 @@ struct PC {
     // 16-row blocks per epilogue pass: bounded by the LDS image and by the registers that hold a pass's prefetched
     // global rows (forward: the residual row, 6 f32 per lane and row; backward: x and g rows, 12)
     static constexpr int ib(int want) { return want < (IB_FIT < FM ? IB_FIT : FM) ? want : (IB_FIT < FM ? IB_FIT : FM); }
+    // MODE_WIDE: the image sits behind ring stage 0 (which holds the next column block's first k-step during the epilogue)
+    static constexpr int ib_wide() { return FM < 3 ? FM : 3; }
+    static constexpr int LDS_WIDE = (STAGE + ib_wide() * 16 * IMG_STRIDE * 4) > LDS ? (STAGE + ib_wide() * 16 * IMG_STRIDE * 4) : LDS;
+    static_assert(LDS_WIDE <= 160 * 1024, "LDS budget (wide)");
     static_assert(IB_FIT >= 1 && LDS * WG_PER_CU <= 160 * 1024, "LDS budget");
     static_assert(NW * 3 * PN * 4 <= LDS, "column-sum reduction scratch must fit the ring");
 };
@@ -71,11 +75,15 @@ struct PanelP {
     const float* gamma; const float* beta; float eps; bf16* y; float* mean; float* rstd;
     // backward
     const float* x; long ldx; float* g; long ldg; bf16* gb; long ldgb; float* partials; int g_init;
+    // wide (plain Linear with N = ncb x 384 output columns, bf16 out): out = epilogue(A W^T) one 384-column block after the other
+    bf16* outb; long ldob; const bf16* aux_in; bf16* aux_out; long ld_aux; int ncb, n_total;
 };
 
-enum { MODE_FWD = 0, MODE_BWD = 1 };
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_WIDE = 2 };
+// MODE_WIDE epilogues (the GV_EPI_* combinations of the hot path's wide products)
+enum { EP_NONE = 0, EP_BIAS = 1, EP_BIAS_GELU = 2, EP_BIAS_GELU_SAVE = 3, EP_DGELU = 4 };
 
-template <int FM, int NW, int BK, bool TB, int MODE>
+template <int FM, int NW, int BK, bool TB, int MODE, int EP = 0>
 __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     using C = PC<FM, NW, BK>;
     constexpr int NF = C::NF;
@@ -89,16 +97,13 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 
     // acc[i][j][r]: row m0 + 16 i + (lane & 15), column 16 (NW j + wave) + 4 (lane >> 4) + r
     f32x4 acc[FM][NF];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     TileSrc<false, C::A_ROWS, BK, NW> srcA;
     TileSrc<TB, 128, BK, NW> srcW[3];
     srcA.setup(p.A, p.lda, m0, M, wave, lane);
+    const int n_total = MODE == MODE_WIDE ? p.n_total : PN;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, PN, wave, lane);
+    for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, n_total, wave, lane);
     const int nt = p.K / BK;
     auto issue = [&](int t) {
         GV_LDS char* st = smem + (t & 1) * C::STAGE;
@@ -108,6 +113,20 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         for (int j = 0; j < 3; ++j) srcW[j].issue(p.ldw, k0, p.K, st + C::A_BYTES + j * C::W_BLOCK, wave);
     };
     issue(0);
+    // MODE_WIDE walks the 384-column blocks of the output with the same row panel: the A rows are staged again per block (from
+    // L2), the block's first ring stage is requested before the previous block's epilogue (whose image lives in stage 1 and
+    // behind it: the k-loop ends in stage 1, nt is even) so the epilogue covers its latency.
+    const int ncb = MODE == MODE_WIDE ? p.ncb : 1;
+    float s_dg[3][2], s_db[3][2], s_g[3][2];          // backward: column sums over this workgroup's rows
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { s_dg[c][e] = 0.f; s_db[c][e] = 0.f; s_g[c][e] = 0.f; }
+    for (int cb = 0; cb < ncb; ++cb) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nt; ++t) {
         wait_vmcnt<0>();                      // my pieces of stage t have landed (nothing younger is in flight yet)
         __builtin_amdgcn_s_barrier();         // everybody's have; every wave is past its reads of stage t - 1
@@ -134,19 +153,26 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     // of the LayerNorm stay inside a wave.  The global rows a pass needs (forward: the residual; backward: x and g, mean,
     // rstd) are all requested BEFORE the pass's image barrier, so their HBM latency overlaps the image traffic and the
     // other rows' arithmetic instead of being paid once per row.
-    constexpr int IB = C::ib(NW == 8 ? (MODE == MODE_FWD ? 5 : 3) : (MODE == MODE_FWD ? 2 : 1));
+    constexpr int IB = MODE == MODE_WIDE ? C::ib_wide() : C::ib(NW == 8 ? (MODE == MODE_FWD ? 5 : 3) : (MODE == MODE_FWD ? 2 : 1));
     constexpr int RPW = 16 * IB / NW;                             // rows per wave and pass
-    GV_LDS float* img = (GV_LDS float*)smem;
+    GV_LDS float* img = (GV_LDS float*)(smem + (MODE == MODE_WIDE ? C::STAGE : 0));
+    constexpr bool HAS_BIAS = MODE == MODE_FWD || (MODE == MODE_WIDE && EP >= EP_BIAS && EP <= EP_BIAS_GELU_SAVE);
     f32x4 bias4[NF];
-    if constexpr (MODE == MODE_FWD) {
+    if constexpr (HAS_BIAS) {
 #pragma unroll
         for (int j = 0; j < NF; ++j)
-            bias4[j] = p.bias ? *(const f32x4*)(p.bias + 16 * (NW * j + wave) + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bias4[j] = p.bias ? *(const f32x4*)(p.bias + cb * PN + 16 * (NW * j + wave) + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (MODE == MODE_WIDE) {
+        if (cb + 1 < ncb) {                   // next block's weights; its first stage goes out now (stage 0 was last read at step nt - 2)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, (cb + 1) * PN + 128 * j, n_total, wave, lane);
+            issue(0);
+        }
     }
     // per-lane column constants of the row phase: lane owns columns (c * 64 + lane) * 2 + {0, 1}, c = 0..2
     float gm[3][2], bt[3][2];
-    float s_dg[3][2], s_db[3][2], s_g[3][2];
-    const bool ln = MODE == MODE_BWD || p.gamma != nullptr;
+    const bool ln = MODE == MODE_BWD || (MODE == MODE_FWD && p.gamma != nullptr);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int col = (c * 64 + lane) * 2;
@@ -154,16 +180,15 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         else { gm[c][0] = gm[c][1] = 1.f; }
         if (MODE == MODE_FWD && ln) { const f32x2 bv = *(const f32x2*)(p.beta + col); bt[c][0] = bv[0]; bt[c][1] = bv[1]; }
         else { bt[c][0] = bt[c][1] = 0.f; }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) { s_dg[c][e] = 0.f; s_db[c][e] = 0.f; s_g[c][e] = 0.f; }
     }
 
 #pragma unroll
     for (int i0 = 0; i0 < FM; i0 += IB) {
         const int ni = (FM - i0) < IB ? (FM - i0) : IB;          // compile-time after unrolling
         // ---- this wave's global rows of the pass (clamped at M: surplus rows load valid memory and are never stored)
-        f32x2 pre_a[RPW][3], pre_b[MODE == MODE_BWD ? RPW : 1][3];
+        f32x2 pre_a[MODE == MODE_WIDE ? 1 : RPW][3], pre_b[MODE == MODE_BWD ? RPW : 1][3];
         float pre_mean[MODE == MODE_BWD ? RPW : 1], pre_rstd[MODE == MODE_BWD ? RPW : 1];
+        bf16x2 pre_x[MODE == MODE_WIDE && EP == EP_DGELU ? RPW : 1][3];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             if (rr < 16 * ni / NW) {
@@ -172,7 +197,9 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int col = (c * 64 + lane) * 2;
-                    if constexpr (MODE == MODE_FWD) {
+                    if constexpr (MODE == MODE_WIDE) {
+                        if constexpr (EP == EP_DGELU) pre_x[rr][c] = *(const bf16x2*)(p.aux_in + (long)m * p.ld_aux + cb * PN + col);
+                    } else if constexpr (MODE == MODE_FWD) {
                         pre_a[rr][c] = p.resid ? *(const f32x2*)(p.resid + (long)m * p.ldr + col) : f32x2{0.f, 0.f};
                     } else {
                         pre_a[rr][c] = *(const f32x2*)(p.x + (long)m * p.ldx + col);
@@ -190,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     f32x4 v = acc[i0 + ii][j];
-                    if constexpr (MODE == MODE_FWD) v += bias4[j];
+                    if constexpr (HAS_BIAS) v += bias4[j];
                     *(GV_LDS f32x4*)(img + (ii * 16 + li16) * IMG_STRIDE + 16 * (NW * j + wave) + gq * 4) = v;
                 }
             }
@@ -209,7 +236,17 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                         const f32x2 t2 = *(GV_LDS f32x2*)(img + r * IMG_STRIDE + (c * 64 + lane) * 2);
                         v[c][0] = t2[0]; v[c][1] = t2[1];
                     }
-                    if constexpr (MODE == MODE_FWD) {
+                    if constexpr (MODE == MODE_WIDE) {
+                        bf16* orow = p.outb + (long)m * p.ldob + cb * PN;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int col = (c * 64 + lane) * 2;
+                            if constexpr (EP == EP_BIAS_GELU_SAVE) *(bf16x2*)(p.aux_out + (long)m * p.ld_aux + cb * PN + col) = bf16x2{(bf16)v[c][0], (bf16)v[c][1]};
+                            if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v[c][0] = gelu_f(v[c][0]); v[c][1] = gelu_f(v[c][1]); }
+                            if constexpr (EP == EP_DGELU) { v[c][0] *= dgelu_f((float)pre_x[rr][c][0]); v[c][1] *= dgelu_f((float)pre_x[rr][c][1]); }
+                            *(bf16x2*)(orow + col) = bf16x2{(bf16)v[c][0], (bf16)v[c][1]};
+                        }
+                    } else if constexpr (MODE == MODE_FWD) {
                         float* orow = p.out + (long)m * p.ldo;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
@@ -269,6 +306,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         }
         __syncthreads();                                          // image free for the next pass / the reduction below
     }
+    }   // column blocks
 
     if constexpr (MODE == MODE_BWD) {
         // column sums over this workgroup's rows -> partials[blockIdx][3][384] (gv_ln_finalize folds them)
@@ -303,38 +341,71 @@ int pick_fm(int M) {
     return 12;
 }
 
-template <int FM, int NW, int BK, bool TB, int MODE>
+template <int FM, int NW, int BK, bool TB, int MODE, int EP = 0>
 int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
-    auto kern = panel_kernel<FM, NW, BK, TB, MODE>;
+    auto kern = panel_kernel<FM, NW, BK, TB, MODE, EP>;
     using C = PC<FM, NW, BK>;
+    constexpr int LDS_BYTES = MODE == MODE_WIDE ? C::LDS_WIDE : C::LDS;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { gv_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     static char kname[96] = "";
-    if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d>", FM, NW, BK, TB ? "true" : "false", MODE);
+    if (!kname[0]) {
+        if (MODE == MODE_WIDE) snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d, %d>", FM, NW, BK, TB ? "true" : "false", MODE, EP);
+        else snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d>", FM, NW, BK, TB ? "true" : "false", MODE);
+    }
     const int grid = (p.M + C::BM - 1) / C::BM;
-    const int th = gvtime::enabled() ? gvtime::begin(kname, 2.0 * p.M * PN * p.K, s) : -1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), C::LDS, s, p);
+    // algorithmic bytes: forward  A row + f32 residual in + f32 row out + bf16 normalised row out + stats;
+    // backward  dY row + f32 x row + f32 g in / out + bf16 g out; + the weight once
+    // wide: A row + the bf16 output row (+ the saved / re-read pre-activation row)
+    const int nout = MODE == MODE_WIDE ? p.n_total : PN;
+    const double row_bytes = MODE == MODE_WIDE ? 2.0 * p.K + 2.0 * nout * ((EP == EP_BIAS_GELU_SAVE || EP == EP_DGELU) ? 2 : 1)
+                             : MODE == MODE_FWD ? 2.0 * p.K + PN * 4 * 2 + PN * 2 + 8 : 2.0 * p.K + PN * 4 * 3 + PN * 2 + 8;
+    const int th = gvtime::enabled() ? gvtime::begin(kname, 2.0 * p.M * nout * p.K, p.M * row_bytes + 2.0 * nout * p.K, s) : -1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS_BYTES, s, p);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK(name);
     return GV_OK;
 }
 
-template <bool TB, int MODE>
+template <bool TB, int MODE, int EP = 0>
 int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
     switch (pick_fm(p.M)) {
-        case 4: return launch_panel<4, 8, 64, TB, MODE>(p, s, name);
-        case 7: return launch_panel<7, 8, 64, TB, MODE>(p, s, name);
-        case 9: return launch_panel<9, 8, 64, TB, MODE>(p, s, name);
-        case 11: return launch_panel<11, 8, 64, TB, MODE>(p, s, name);
-        default: return launch_panel<12, 8, 64, TB, MODE>(p, s, name);
+        case 4: return launch_panel<4, 8, 64, TB, MODE, EP>(p, s, name);
+        case 7: return launch_panel<7, 8, 64, TB, MODE, EP>(p, s, name);
+        case 9: return launch_panel<9, 8, 64, TB, MODE, EP>(p, s, name);
+        case 11: return launch_panel<11, 8, 64, TB, MODE, EP>(p, s, name);
+        default: return launch_panel<12, 8, 64, TB, MODE, EP>(p, s, name);
     }
 }
 
 }  // namespace
+
+// gv_linear's wide products (timing.h): C[M, N] bf16 = epilogue(A W^T) with N a multiple of 384, K a multiple of 128 and one of
+// the hot path's epilogues, on the full-row kernel -- row panels sized for ONE round of workgroups, 768-B row segments out.
+// Returns -1 when the call is not one of these (the caller then runs the 128x128-tile kernel).
+int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
+    if (a->trans_a || a->c_is_f32 || a->N % PN != 0 || a->K % 128 != 0 || a->M < 2048 || a->ldc % 2 != 0) return -1;
+    if (a->alpha != 0.f && a->alpha != 1.f) return -1;
+    PanelP p{};
+    p.A = (const bf16*)a->A; p.W = (const bf16*)a->B; p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldb;
+    p.bias = a->bias; p.outb = (bf16*)a->C; p.ldob = a->ldc; p.aux_in = (const bf16*)a->aux_in; p.aux_out = (bf16*)a->aux_out; p.ld_aux = a->ld_aux;
+    p.ncb = a->N / PN; p.n_total = a->N;
+    if (a->ld_aux % 2 != 0) return -1;
+    const int e = a->epilogue;
+    if (!a->trans_b) {
+        if (e == GV_EPI_BIAS) return dispatch_fm<false, MODE_WIDE, EP_BIAS>(p, s, "gv_linear(wide)");
+        if (e == (GV_EPI_BIAS | GV_EPI_GELU)) return dispatch_fm<false, MODE_WIDE, EP_BIAS_GELU>(p, s, "gv_linear(wide)");
+        if (e == (GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE)) return dispatch_fm<false, MODE_WIDE, EP_BIAS_GELU_SAVE>(p, s, "gv_linear(wide)");
+    } else {
+        if (e == 0) return dispatch_fm<true, MODE_WIDE, EP_NONE>(p, s, "gv_linear(wide)");
+        if (e == GV_EPI_DGELU) return dispatch_fm<true, MODE_WIDE, EP_DGELU>(p, s, "gv_linear(wide)");
+    }
+    return -1;
+}
 
 extern "C" int gv_linear_ln_blocks(int32_t M) {
     if (M <= 0) return 0;

@@ -6,6 +6,9 @@
 namespace gvtime {
 bool enabled();
 // records the start event on `s`; returns a handle for end() (or -1 when timing is off)
-int begin(const char* kernel_name, double flops, hipStream_t s);
+int begin(const char* kernel_name, double flops, double bytes, hipStream_t s);
 void end(int handle, hipStream_t s);
 }  // namespace gvtime
+
+// panel.hip: gv_linear's wide bf16 products on the full-row kernel; -1 = not one of them
+int gv_panel_wide(const gv_linear_args* a, hipStream_t s);

@@ -147,12 +147,12 @@ def linear_timing(enable: bool):
 
 
 def linear_timing_read():
-    """Rows {kernel, launches, seconds, flops} per GEMM-class kernel since linear_timing(True)."""
+    """Rows {kernel, launches, seconds, flops, bytes} per GEMM-class kernel since linear_timing(True)."""
     rows = (L.gv_linear_timing_row * 64)()
     n = L.lib.gv_linear_timing_read(rows, 64)
     if n < 0 or n > 64:
         raise L.GipvitError(f"gv_linear_timing_read: {n}: {L.lib.gv_last_error().decode()}")
-    return [{"kernel": r.name.decode(), "launches": r.launches, "seconds": r.seconds, "flops": r.flops} for r in rows[:n]]
+    return [{"kernel": r.name.decode(), "launches": r.launches, "seconds": r.seconds, "flops": r.flops, "bytes": r.bytes} for r in rows[:n]]
 
 
 def linear_ln_fwd(A, W, out, M: int, K: int, *, bias=None, resid=None, gamma=None, beta=None, y=None, mean=None, rstd=None, eps: float = 1e-6,

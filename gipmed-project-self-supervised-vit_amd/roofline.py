@@ -1,15 +1,16 @@
 """Live roofline measurement of the dominant kernel for bench.py's JSON line.
 
-The step is MFMA-bound as a whole (98.7 % of FLOPs are dense contractions) and its
-dominant kernels are instantiations of the bf16 MFMA GEMM behind gv_linear.  After the timed
-region bench.py runs a few more steps of the SAME workload with gv_linear_timing enabled: the
-library brackets every GEMM launch with two HIP events on the launch stream and folds them
-into one row per kernel instantiation.  The dominant kernel is the row with the largest summed
-time; achieved = its algorithmic FLOPs (2*M*N*K of every launch) / its summed duration, i.e.
-average FLOPs per launch / average launch duration -- the average rocprofv3 --kernel-trace
---stats reports for the same kernel name must agree (profiles/).  `traffic` is the HBM bytes
-per launch of that kernel from the committed PMC passes (FETCH_SIZE doubled per the gfx950
-correction + WRITE_SIZE), looked up in profiles/*_hbm_traffic_per_kernel.json."""
+98.7 % of the step's FLOPs are dense contractions and its dominant kernels are the bf16 MFMA
+GEMM-class kernels behind gv_linear / gv_linear_ln_* / gv_linear_dw_group.  After the timed region bench.py
+runs a few more steps of the SAME workload with gv_linear_timing enabled: the library brackets every such
+launch with two HIP events on the launch stream and folds them into one row per kernel instantiation, with
+the launch's algorithmic FLOPs (2*M*N*K) and algorithmic HBM bytes (every operand read once, every output
+written once).  The dominant kernel is the row with the largest summed time.  Which roof bounds it follows
+from its arithmetic intensity against the machine balance (2500 TFLOP/s / 8 TB/s = 312 FLOP/B): below it the
+kernel is priced against HBM (achieved = algorithmic bytes / time), above it against the dense bf16 MFMA
+peak; both fractions are reported.  The average launch duration must agree with what rocprofv3 --kernel-trace
+--stats reports for the same kernel name (profiles/).  `traffic` is the measured HBM bytes per launch of that
+kernel from the committed PMC passes, looked up in profiles/*_hbm_traffic_per_kernel.json."""
 from __future__ import annotations
 
 import glob
@@ -21,6 +22,7 @@ import torch
 from . import ops
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md, HBM3E
 
 
 def _traffic_for(kernel: str):
@@ -72,11 +74,18 @@ def dominant_kernel_roofline(step_fn, steps: int = 3, vit=None):
     else:
         rows = _timed_rows(step_fn, steps)
     table = [{"kernel": r["kernel"], "launches_per_step": round(r["launches"] / steps, 2), "avg_us": round(r["seconds"] / r["launches"] * 1e6, 2),
-              "ms_per_step": round(r["seconds"] / steps * 1e3, 3), "tflops": round(r["flops"] / r["seconds"] / 1e12, 1)} for r in rows]
+              "ms_per_step": round(r["seconds"] / steps * 1e3, 3), "tflops": round(r["flops"] / r["seconds"] / 1e12, 1),
+              "gbs": round(r["bytes"] / r["seconds"] / 1e9, 0)} for r in rows]
     d = rows[0]
-    ach = d["flops"] / d["seconds"] / 1e12
+    tf, gbs = d["flops"] / d["seconds"] / 1e12, d["bytes"] / d["seconds"] / 1e9
+    hbm_bound = d["bytes"] > 0 and d["flops"] / d["bytes"] < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS
     traffic, src = _traffic_for(d["kernel"])
-    return {"bound": "mfma", "kernel": d["kernel"], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+    head = ({"bound": "hbm", "kernel": d["kernel"], "achieved": round(gbs, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+            if hbm_bound else
+            {"bound": "mfma", "kernel": d["kernel"], "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)})
+    return {**head, "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+            "flop_per_byte": round(d["flops"] / d["bytes"], 1) if d["bytes"] > 0 else None,
+            "avg_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 2),
+            "traffic": traffic, "traffic_source": src,
             "launches_per_step": round(d["launches"] / steps, 2), "avg_launch_us": round(d["seconds"] / d["launches"] * 1e6, 2),
             "avg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3), "timed_steps": steps, "in_step": in_step, "gemm_kernels": table}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 3
+#define GV_ABI_VERSION 4
 enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
        GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
@@ -238,6 +238,7 @@ typedef struct {
     char name[96];
     int32_t launches;
     double seconds, flops;   /* summed over the launches */
+    double bytes;            /* algorithmic HBM bytes summed over the launches: every operand read once, every output written once */
 } gv_linear_timing_row;
 int gv_linear_timing(int enable);
 int gv_linear_timing_read(gv_linear_timing_row* rows, int max_rows);

@@ -108,6 +108,46 @@ def test_linear_epilogues(dev):
     close(Cf, 0.25 * (A.float() @ B.float().t()), 1e-4, 1e-4, "alpha")
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 384, 128), (2500, 1152, 384), (4099, 1536, 384), (3000, 384, 1536)])
+def test_linear_wide_panel(dev, M, N, K):
+    """gv_linear's wide bf16 products (M >= 2048, N % 384 == 0, K % 128 == 0, hot-path epilogues) run on the full-row kernel:
+    exact on integer data (NT and NN forms, ragged last row panel), epilogues against fp32 torch, and identical to the
+    128x128-tile kernel's result on the same operands (a sub-range of rows below the M threshold)."""
+    o, l = ops(), L()
+    A, B = ints((M, K), dev, seed=31), ints((N, K), dev, seed=32)
+    bias_i = torch.arange(N, dtype=f32, device=dev) % 5 - 2
+    ref = A.float() @ B.float().t()
+    Cb = torch.full((M + 1, N), 9.0, dtype=bf16, device=dev)                  # one guard row behind the output
+    o.linear(A, B, Cb, M, N, K, epilogue=l.EPI_BIAS, bias=bias_i)
+    assert torch.equal(Cb[:M].float(), (ref + bias_i).to(bf16).float()) and float(Cb[M].float().min()) == 9.0
+    Bt = B.t().contiguous()                                                  # dX form: B stored [K, N]
+    o.linear(A, Bt, Cb, M, N, K, trans_b=True)
+    assert torch.equal(Cb[:M].float(), ref.to(bf16).float()) and float(Cb[M].float().min()) == 9.0
+    # float data: GELU / saved pre-activation / GELU' epilogues
+    g = torch.Generator().manual_seed(33)
+    Af = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(bf16)
+    Bf = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(bf16)
+    bias = torch.randn(N, generator=g).to(dev)
+    reff = Af.float() @ Bf.float().t() + bias
+    C = torch.empty(M, N, dtype=bf16, device=dev); pre = torch.empty(M, N, dtype=bf16, device=dev)
+    o.linear(Af, Bf, C, M, N, K, epilogue=l.EPI_BIAS | l.EPI_GELU | l.EPI_SAVE_PRE, bias=bias, aux_out=pre)
+    close(pre, reff, 1e-2, 1e-2, "pre")
+    close(C, torch.nn.functional.gelu(reff), 1e-2, 1e-2, "gelu")
+    C2 = torch.empty(M, N, dtype=bf16, device=dev)
+    o.linear(Af, Bf, C2, M, N, K, epilogue=l.EPI_BIAS | l.EPI_GELU, bias=bias)
+    assert torch.equal(C2, C)
+    aux = torch.randn(M, N, generator=g).to(dev).to(bf16)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    Bft = Bf.t().contiguous()
+    o.linear(Af, Bft, C, M, N, K, trans_b=True, epilogue=l.EPI_DGELU, aux_in=aux)
+    close(C, (reff - bias) * x.grad, 1e-2, 1e-2, "dgelu")
+    # the 128x128-tile kernel on the first 1000 rows (below the threshold) gives the same bits
+    Cs = torch.empty(1000, N, dtype=bf16, device=dev)
+    o.linear(Af, Bft, Cs, 1000, N, K, trans_b=True, epilogue=l.EPI_DGELU, aux_in=aux)
+    assert torch.equal(Cs, C[:1000])
+
+
 def test_linear_pos_epilogue(dev):
     """patch-embed epilogue: rows remapped past the CLS slot, pos-embed added."""
     o, l = ops(), L()
@@ -148,6 +188,8 @@ def test_linear_timing_rows(dev):
     rows = {r["kernel"]: r for r in o.linear_timing_read()}
     nt = rows["gemm_kernel<false, false, bf16, false, 0>"]
     tn = rows["gemm_kernel<true, true, float, false, 0>"]
+    assert nt["bytes"] == 3 * 2.0 * (256 * 384 + 128 * 384 + 256 * 128)      # algorithmic bytes: operands and output once
+    assert tn["bytes"] == 2.0 * 256 * (384 + 128) + 4.0 * 384 * 128
     assert len(rows) == 2 and nt["launches"] == 3 and tn["launches"] == 1
     assert nt["flops"] == 3 * 2.0 * 256 * 128 * 384 and tn["flops"] == 2.0 * 384 * 128 * 256
     assert 0.0 < nt["seconds"] < 1.0 and 0.0 < tn["seconds"] < 1.0
