@@ -187,7 +187,7 @@ int launch_dw8(const Dw8P& q, float* C, long ldc, int M, int N, hipStream_t s) {
         if (e != hipSuccess) { gv_set_error("gemm(dw8): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    const int th = gvtime::enabled() ? gvtime::begin(SWAP ? "dw8_kernel<swapped>" : "dw8_kernel<normal>", 2.0 * M * N * q.K, 2.0 * q.K * ((double)M + N) + 8.0 * M * N, s) : -1;
+    const int th = gvtime::enabled() ? gvtime::begin(SWAP ? "dw8_kernel<true, 0>" : "dw8_kernel<false, 0>", 2.0 * M * N * q.K, 2.0 * q.K * ((double)M + N) + 8.0 * M * N, s) : -1;
     hipLaunchKernelGGL(kern, dim3(q.tiles_p * q.tiles_q * q.ksplit), dim3(512), DW8_LDS, s, q);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK("gv_linear(dw8)");

@@ -353,10 +353,7 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
         attr_done = true;
     }
     static char kname[96] = "";
-    if (!kname[0]) {
-        if (MODE == MODE_WIDE) snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d, %d>", FM, NW, BK, TB ? "true" : "false", MODE, EP);
-        else snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d>", FM, NW, BK, TB ? "true" : "false", MODE);
-    }
+    if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d, %d>", FM, NW, BK, TB ? "true" : "false", MODE, EP);   // as rocprofv3 prints it
     const int grid = (p.M + C::BM - 1) / C::BM;
     // algorithmic bytes: forward  A row + f32 residual in + f32 row out + bf16 normalised row out + stats;
     // backward  dY row + f32 x row + f32 g in / out + bf16 g out; + the weight once

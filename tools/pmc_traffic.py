@@ -22,7 +22,7 @@ def canon(name: str) -> str:
         epi = m.group(5).replace("n", "-")
         return f"gemm_kernel<{b(m.group(1))}, {b(m.group(2))}, {'bf16' if m.group(3) == 'DF16b' else 'float'}, {b(m.group(4))}, {epi}>"
     name = re.sub(r"^void\s+", "", name)
-    name = name.replace("(anonymous namespace)::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("gvgemm::", "")
     name = re.sub(r"\(.*\)$", "", name)
     return name.replace("__hip_bfloat16", "bf16")
 
