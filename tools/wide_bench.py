@@ -38,3 +38,14 @@ for M in (44160, 25216):
         t = timeit(lambda: o.linear(A, Wk, C, M, N, 384, **kw))
         by = M * 384 * 2 + M * N * 2 * (2 if epi & (L.EPI_SAVE_PRE | L.EPI_DGELU) else 1)
         print(f"M {M} {name:12s} N {N}: {t[0]:6.1f} us (min {t[1]:6.1f}) = {by / t[0] / 1e6:5.2f} TB/s, {2.0 * M * N * 384 / t[0] / 1e6:5.0f} TF", flush=True)
+
+# k-loop vs epilogue: the same output with growing K (slope = time per 64-deep k-step of all column blocks, intercept = epilogues)
+M = 44160
+for N, epi, name in ((1536, L.EPI_BIAS | L.EPI_GELU | L.EPI_SAVE_PRE, "fc1-like"), (1152, L.EPI_BIAS, "qkv-like")):
+    for K in (128, 384, 768, 1536):
+        A = torch.randn(M, K, generator=g).to(dev).to(bf16)
+        W = (0.05 * torch.randn(N, K, generator=g)).to(dev).to(bf16)
+        bias = torch.randn(N, generator=g).to(dev)
+        C = torch.empty(M, N, dtype=bf16, device=dev); aux = torch.empty(M, N, dtype=bf16, device=dev)
+        t = timeit(lambda: o.linear(A, W, C, M, N, K, epilogue=epi, bias=bias, aux_out=aux if epi & L.EPI_SAVE_PRE else None))
+        print(f"{name} N {N} K {K:5d}: {t[0]:6.1f} us (min {t[1]:6.1f})  {2.0 * M * N * K / t[0] / 1e6:5.0f} TF", flush=True)
