@@ -114,3 +114,124 @@ def load_encoder_checkpoint(path: str, arch: str, img_size: int, num_classes: in
             t = fresh[name]
         out[name] = t.float()
     return out
+
+
+# --------------------------------------------------------------------------- #
+# the model-object seam of the reference driver (train.py:482-510, 615-622, 1045)
+# --------------------------------------------------------------------------- #
+class Param:
+    """What the reference touches on a parameter: ``.data`` (an f32 view into the engine's arena), ``.requires_grad``
+    (train.py:497-503 sets it), ``.shape`` / ``.numel()`` (the parameter-count log line, train.py:512-514)."""
+
+    def __init__(self, name: str, data: torch.Tensor):
+        self.name, self.data, self.requires_grad = name, data, True
+        self.shape = data.shape
+
+    def numel(self) -> int:
+        return self.data.numel()
+
+
+class _Head:
+    """``model.head`` (timm's classifier ``nn.Linear``): ``.weight`` / ``.bias`` / ``.parameters()`` (train.py:500-502)."""
+
+    def __init__(self, weight: Param, bias: Param):
+        self.weight, self.bias = weight, bias
+        self.in_features, self.out_features = weight.shape[1], weight.shape[0]
+
+    def parameters(self):
+        return iter((self.weight, self.bias))
+
+
+class VitModel:
+    """The object ``create_model`` returns: the attributes and methods the reference driver uses on timm's
+    ``VisionTransformer`` (``num_classes``, ``head``, ``no_weight_decay()``, ``set_grad_checkpointing()``, ``parameters()``,
+    ``state_dict()`` / ``load_state_dict()``, ``train()`` / ``eval()``, ``model(input)``), backed by a ``SupervisedEngine``
+    (the hot path itself: HIP kernels behind the C ABI, explicit backward -- there is no ``nn.Module`` and no autograd)."""
+
+    def __init__(self, engine, arch: str):
+        self.engine, self.arch = engine, arch
+        self.num_classes, self.embed_dim, self.num_features = engine.C, engine.D, engine.D
+        a = engine.arena
+        self._params = OrderedDict((n, Param(n, a.view(a.p, n))) for n in a.specs)
+        self.head = _Head(self._params["head.weight"], self._params["head.bias"])
+        self.training = True
+
+    def parameters(self):
+        return iter(self._params.values())
+
+    def named_parameters(self):
+        return iter(self._params.items())
+
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token"}               # vit.pyc@L208-211
+
+    def set_grad_checkpointing(self, enable: bool = True):
+        # the explicit backward keeps every block's activations resident (4 GB at B = 64 on a 288-GB part): nothing to do
+        self.grad_checkpointing = bool(enable)
+
+    @property
+    def backbone_trainable(self) -> bool:
+        """False after the reference's ``--no-grad`` pattern (every parameter frozen, then the head's re-enabled)."""
+        return any(p.requires_grad for n, p in self._params.items() if not n.startswith("head."))
+
+    def apply_requires_grad(self):
+        """Hand the ``requires_grad`` flags to the engine (it steps either everything or the classifier only)."""
+        head_on = self.head.weight.requires_grad and self.head.bias.requires_grad
+        if not head_on:
+            raise ValueError("a frozen classifier head is not a configuration of the reference driver")
+        self.engine.train_backbone = self.backbone_trainable
+        return self
+
+    def state_dict(self):
+        return self.engine.state_dict()
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True):
+        want = set(self._params)
+        missing, extra = sorted(want - set(state)), sorted(set(state) - want)
+        if strict and (missing or extra):
+            raise KeyError(f"load_state_dict: missing {missing[:4]}, unexpected {extra[:4]}")
+        cur = self.engine.state_dict()
+        cur.update({k: v for k, v in state.items() if k in want})
+        self.engine.load_state(cur)
+        return missing, extra
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def cuda(self, *a, **k):
+        return self
+
+    to = cuda
+
+    def forward_features(self, tiles_u8: torch.Tensor) -> torch.Tensor:
+        return self.engine.forward(tiles_u8)[1]
+
+    def __call__(self, tiles_u8: torch.Tensor) -> torch.Tensor:
+        """NHWC uint8 tiles [batch, H, W, 3] already on the device -> logits f32 [batch, num_classes] (the engine's buffer)."""
+        return self.engine.forward(tiles_u8)[0]
+
+
+def create_model(model_name: str, pretrained: bool = False, in_chans: int = 3, num_classes: Optional[int] = None,
+                 drop_rate: float = 0.0, drop_path_rate: Optional[float] = None, checkpoint_path: str = "",
+                 img_size: int = 256, batch: int = 8, device: str = "cuda:0", seed: int = 0, **engine_kwargs) -> VitModel:
+    """Counterpart of ``timm.create_model`` as the reference calls it (train.py:482-495) for the ViT names it documents.
+    Unsupported requests fail here instead of being ignored: other channel counts, dropout / stochastic depth (not built),
+    ``pretrained`` without a checkpoint file (there is no network).  ``num_classes=None`` keeps the checkpoint-less default
+    of the reference's runs (2 classes, train_instruct.txt:16-34)."""
+    from .engine import SupervisedEngine
+    arch = resolve_arch(model_name)
+    if in_chans != 3:
+        raise ValueError(f"create_model: in_chans={in_chans}; the hot path is built for RGB tiles")
+    if drop_rate or drop_path_rate:
+        raise ValueError("create_model: dropout / drop-path are not built (DESIGN.md section 6)")
+    if pretrained and not checkpoint_path:
+        raise ValueError("create_model: pretrained=True needs checkpoint_path (no network on this system)")
+    C = 2 if num_classes is None else int(num_classes)
+    eng = SupervisedEngine(arch=arch, img_size=img_size, num_classes=C, batch=batch, device=device, **engine_kwargs)
+    state = load_encoder_checkpoint(checkpoint_path, arch, img_size, C) if checkpoint_path else init_vit_state(arch, img_size, C, seed=seed)
+    eng.load_state(state)
+    return VitModel(eng, arch)

@@ -130,20 +130,22 @@ def test_dino_forward_backward_parity_configs(dev, arch, n_local, B, K):
 
 
 @gpu
-def test_dino_micro_batches_equal_full_batch(dev):
-    """Gradient accumulation (BASELINE config 5 micro-batches 512 tiles per GPU): one optimizer step
-    over two micro-batches of 1 tile equals the step on the 2-tile batch up to summation order."""
+@pytest.mark.parametrize("arch,D,mb", [("vit_tiny", 192, 1), ("vit_base", 768, 8)])
+def test_dino_micro_batches_equal_full_batch(dev, arch, D, mb):
+    """Gradient accumulation (BASELINE config 5: ViT-B, 512 tiles per GPU in micro-batches): one optimizer step
+    over two micro-batches of `mb` tiles equals the step on the 2 mb-tile batch up to summation order.  At mb = 8 ViT-B's
+    products run the kernels of the large-batch path (wide full-row products, grouped ping-pong weight gradients)."""
     from gipvit.engine import DinoEngine
     from oracle import vit_oracle as vo
     K = 1024
-    p, hp = vo.init_vit("vit_tiny", 224, 0, seed=0), vo.init_dino_head(192, K, seed=1)
-    tiles = vo.synth_tiles(2, 256, seed=5).to(dev)
-    full = DinoEngine(arch="vit_tiny", img_size=224, out_dim=K, batch=2, lr=1e-4, clip_grad=3.0, device=dev)
-    micro = DinoEngine(arch="vit_tiny", img_size=224, out_dim=K, batch=1, lr=1e-4, clip_grad=3.0, device=dev)
+    p, hp = vo.init_vit(arch, 224, 0, seed=0), vo.init_dino_head(D, K, seed=1)
+    tiles = vo.synth_tiles(2 * mb, 256, seed=5).to(dev)
+    full = DinoEngine(arch=arch, img_size=224, out_dim=K, batch=2 * mb, lr=1e-4, clip_grad=3.0, device=dev)
+    micro = DinoEngine(arch=arch, img_size=224, out_dim=K, batch=mb, lr=1e-4, clip_grad=3.0, device=dev)
     full.load_state(p, hp); micro.load_state(p, hp)
     for _ in range(2):
         lf = full.step(tiles)
-        lm = micro.step_micro([tiles[0:1], tiles[1:2]])
+        lm = micro.step_micro([tiles[0:mb], tiles[mb:2 * mb]])
         torch.cuda.synchronize()
         assert abs(float(lf) - float(lm)) <= 2e-3, (float(lf), float(lm))
     assert _rel(micro.center, full.center) < 1e-3
@@ -295,3 +297,38 @@ def test_golden_dino_tiny(dev):
     assert _rel(gr["backbone.pos_embed"][0, :4, :32], torch.from_numpy(gold["g_pos"])) <= 5e-2
     gn = math.sqrt(sum(float((g.double() ** 2).sum()) for g in gr.values()))
     assert abs(gn - float(gold["grad_norm"])) <= 1e-2 * float(gold["grad_norm"])
+
+
+@gpu
+def test_create_model_seam(dev):
+    """models.create_model: the model-object seam of the reference driver (train.py:482-510) over the engine."""
+    from gipvit import models
+    from gipvit.engine import SupervisedEngine, vit_param_specs
+    from oracle import vit_oracle as vo
+    m = models.create_model("vit_tiny_patch16_224", num_classes=3, img_size=64, batch=8, device=dev)
+    assert m.num_classes == 3 and m.head.out_features == 3 and m.head.in_features == 192 and m.embed_dim == 192
+    assert m.no_weight_decay() == {"pos_embed", "cls_token"}
+    assert list(m.state_dict()) == list(vit_param_specs("vit_tiny", 64, 3))
+    assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in m.state_dict().values())
+    m.set_grad_checkpointing(enable=True)
+    # the reference's --no-grad pattern (train.py:497-503)
+    for p in m.parameters():
+        p.requires_grad = False
+    for p in m.head.parameters():
+        p.requires_grad = True
+    assert not m.backbone_trainable and m.apply_requires_grad().engine.train_backbone is False
+    # model(input) = the engine's forward on the same weights; load_state_dict round trip
+    tiles = vo.synth_tiles(8, 64, seed=3).to(dev)
+    ref = SupervisedEngine(arch="vit_tiny", img_size=64, num_classes=3, batch=8, device=dev)
+    ref.load_state(m.state_dict())
+    assert torch.equal(m.eval()(tiles), ref.forward(tiles)[0])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["head.bias"] += 1.0
+    m.load_state_dict(sd)
+    assert torch.allclose(m(tiles), ref.forward(tiles)[0] + 1.0, atol=1e-5)
+    with pytest.raises(KeyError):
+        m.load_state_dict({"head.bias": sd["head.bias"]})
+    with pytest.raises(ValueError, match="drop"):
+        models.create_model("vit_tiny", drop_path_rate=0.1, device=dev)
+    with pytest.raises(ValueError, match="checkpoint_path"):
+        models.create_model("vit_tiny", pretrained=True, device=dev)

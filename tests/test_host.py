@@ -307,3 +307,16 @@ def test_lr_schedule_and_checkpoint_saver(tmp_path):
     assert names == ["checkpoint-1.pth.tar", "checkpoint-2.pth.tar", "last.pth.tar", "model_best.pth.tar"]
     ck = load_checkpoint_file(str(tmp_path / "model_best.pth.tar"))          # weights_only loader
     assert ck["epoch"] == 1 and ck["version"] == 2 and ck["arch"] == "vit_tiny" and ck["args"] == {"lr": 0.1} and ck["metric"] == 1.0
+
+
+def test_create_model_rejects_what_is_not_built():
+    """models.create_model (the reference's create_model seam) refuses unsupported requests before touching a GPU."""
+    from gipvit import models
+    with pytest.raises(ValueError, match="unknown model"):
+        models.create_model("resnet50")
+    with pytest.raises(ValueError, match="in_chans"):
+        models.create_model("vit_tiny", in_chans=1)
+    with pytest.raises(ValueError, match="drop"):
+        models.create_model("vit_small_patch16_224", drop_rate=0.1)
+    with pytest.raises(ValueError, match="checkpoint_path"):
+        models.create_model("vit_small_patch16_224", pretrained=True)
