@@ -161,7 +161,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const ReduceGr
     }
 }
 
-constexpr long WORKSPACE_BYTES = 64L << 20;
+constexpr long WORKSPACE_BYTES = 128L << 20;
+
+// k-slices for `tiles` one-per-CU workgroups over `ktiles` 64-deep K-tiles: the S that minimises  rounds of 256 workgroups x
+// K-tiles per slice  (ViT-S block: 36 tiles -> S = 7, one round; ViT-B block: 144 tiles -> S = 3, two rounds of 2/3 the
+// depth of S = 1), smallest S on ties, at least four K-tiles per slice, slabs within the workspace
+int dw8_pick_slices(int tiles, int ktiles, long mn_floats, long workspace_bytes) {
+    int best = 1; long best_cost = -1;
+    for (int S = 1; S <= 64; ++S) {
+        if (S > 1 && (ktiles / S < 4 || (long)S * mn_floats * 4 > workspace_bytes)) break;
+        const long cost = (long)((tiles * S + 255) / 256) * ((ktiles + S - 1) / S);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = S; }
+    }
+    return best;
+}
 
 // dW over many token rows on the 8-wave ping-pong kernel (gemm_dw8.h).  Returns -1 when the shape is not one of its own
 // (the caller then takes the 128x128 split-K path), else the launch status.
@@ -218,10 +231,8 @@ int try_dw8(const gv_linear_args* a, hipStream_t s) {
     q.tiles_p = q.Pn / 128; q.tiles_q = q.Qn / 384;
     const int tiles = q.tiles_p * q.tiles_q;
     if (tiles > 256) return -1;
-    // one workgroup per CU and never a second round: S = floor(256 / tiles) slices of at least four K-tiles
     const int ktiles = (a->K + 63) / 64;
-    const int want = 256 / tiles, maxs = ktiles / 4 > 0 ? ktiles / 4 : 1;
-    int S = want < maxs ? want : maxs;
+    int S = dw8_pick_slices(tiles, ktiles, (long)a->M * a->N, a->workspace_bytes);
     const int per = (ktiles + S - 1) / S;
     S = (ktiles + per - 1) / per;
     if ((long)S * a->M * a->N * 4 > a->workspace_bytes) return -1;
@@ -434,8 +445,9 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
         }
         if (ok8 && tiles8 <= 256) {
             const int ktiles = (a->K + 63) / 64;
-            const int want = 256 / tiles8, maxs = ktiles / 4 > 0 ? ktiles / 4 : 1;
-            int S = want < maxs ? want : maxs;
+            long mn = 0;
+            for (int q = 0; q < a->n; ++q) mn += (long)a->prob[q].M * a->prob[q].N;
+            int S = dw8_pick_slices(tiles8, ktiles, mn, a->workspace_bytes);
             const int per = (ktiles + S - 1) / S;
             S = (ktiles + per - 1) / per;
             Dw8GroupP G8{};

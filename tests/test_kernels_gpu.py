@@ -56,7 +56,7 @@ def test_linear_nn_exact(dev, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (384, 1152, 394), (1536, 384, 1000), (192, 576, 37 * 8 + 5), (256, 256, 8192),
-                                   (1536, 384, 6000), (1152, 384, 4100), (384, 1536, 5008), (2048, 384, 4096)])
+                                   (1536, 384, 6000), (1152, 384, 4100), (384, 1536, 5008), (2048, 384, 4096), (384, 1664, 4160), (768, 3072, 2560)])
 def test_linear_tn_exact(dev, M, N, K):
     """dW = dY^T X : A stored [K,M], B stored [K,N]; K = tokens (any length)."""
     A, B = ints((K, M), dev, -1, 2, seed=5), ints((K, N), dev, -1, 2, seed=6)
@@ -75,7 +75,8 @@ def test_linear_tn_exact(dev, M, N, K):
     C3 = torch.ones(M, N, dtype=f32, device=dev)
     cs3 = torch.full((M,), 2.0, device=dev)
     ops().linear(A, B, C3, M, N, K, trans_a=True, trans_b=True, epilogue=L().EPI_ACCUM, workspace=ws, colsum_a=cs3)
-    assert torch.equal(C3, ref + 1.0)           # K >= 4096 with a long side >= 1024 runs the 256x128 / 128x256 tiles
+    # K >= 2048 with M % 128 == 0, N % 384 == 0 runs the ping-pong kernel; (384, 1664): its swapped orientation (C = [Q x P])
+    assert torch.equal(C3, ref + 1.0)
     assert torch.equal(cs3, 2.0 + A.float().sum(0))
 
 
