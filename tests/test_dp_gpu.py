@@ -62,7 +62,10 @@ def test_two_ranks_match_single_process(dev):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 1000
+    import socket
+    with socket.socket() as sk:              # a port the kernel reports free (a pid-derived one collided now and then)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=300) for _ in ps], key=lambda t: t[0])

@@ -121,7 +121,10 @@ def test_reducer_world_size_2_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    import socket
+    with socket.socket() as sk:              # a port the kernel reports free (a pid-derived one collided now and then)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
