@@ -48,21 +48,6 @@ constexpr int DW8_IMG = 64 * 128 * 2;
 constexpr int DW8_STAGE = 4 * DW8_IMG;
 constexpr int DW8_LDS = 2 * DW8_STAGE;
 
-// LDS-DMA of 16 B per lane with the global address split as  uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset (VGPR)
-// + immediate: the k-loop advances only the scalar base, the issuing wave spends no vector instruction on addresses (its SIMD
-// partner is inside an MFMA cluster at raised priority: every VALU instruction of the load segment waits for a free issue slot)
-// (the instruction's immediate offset is added to the LDS address as well as to the global one, as for MUBUF LDS loads:
-// M0 is set IMM short of the destination)
-template <int IMM>
-__device__ __forceinline__ void glds16_s(unsigned long long sbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    lds_dst -= IMM;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
-                 : "memory");
-}
-
 #ifdef GV_DW8_STAMPS
 #define DW8_STAMP(v) const unsigned long long v = dw8_stamp()
 __device__ __forceinline__ unsigned long long dw8_stamp() {

@@ -24,6 +24,7 @@
 // a pass needs are all requested before the pass's image barrier.
 #include "gemm_core.h"
 #include "timing.h"
+#include <type_traits>
 
 namespace {
 
@@ -68,6 +69,11 @@ struct PC {
 // So neither the SIMD partners' phase alignment nor the depth of the A stream is what holds the loop at ~55 % of its MFMA
 // time; the LDS fragment traffic (every wave reads all of A: 224 KB per 64-deep step and CU) is the next suspect.
 
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); static_for<LO + 1, HI>(f); }
+}
+
 struct PanelP {
     const bf16* A; const bf16* W; int M, K; long lda, ldw;
     // forward
@@ -83,10 +89,15 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_WIDE = 2 };
 // MODE_WIDE epilogues (the GV_EPI_* combinations of the hot path's wide products)
 enum { EP_NONE = 0, EP_BIAS = 1, EP_BIAS_GELU = 2, EP_BIAS_GELU_SAVE = 3, EP_DGELU = 4 };
 
-template <int FM, int NW, int BK, bool TB, int MODE, int EP = 0>
+// PP = 1: the k-loop of gemm_dw8.h (ping-pong halves, three phases per 64-deep K-tile, counted LDS-DMA stream) instead of the
+// one-stage-ahead loop: waves (wm, wn) = (wave >> 2, wave & 3); the wm = 0 half owns the first FMH = ceil(FM / 2) row fragments,
+// the wm = 1 half the rest; in weight block b (phase b of a K-tile) a wave owns column fragments {2 wn, 2 wn + 1}.
+template <int FM, int NW, int BK, bool TB, int MODE, int EP = 0, int PP = 0>
 __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     using C = PC<FM, NW, BK>;
     constexpr int NF = C::NF;
+    static_assert(!PP || (NW == 8 && BK == 64), "ping-pong loop: 8 waves, BK = 64");
+    constexpr int FMH = (FM + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GV_LDS char* smem = (GV_LDS char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,15 +107,46 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     const int M = p.M;
 
     // acc[i][j][r]: row m0 + 16 i + (lane & 15), column 16 (NW j + wave) + 4 (lane >> 4) + r
-    f32x4 acc[FM][NF];
+    f32x4 acc[PP ? 1 : FM][NF];
+    // PP: acc8[b][i][j][r]: row m0 + 16 (wm FMH + i) + (lane & 15), column 128 b + 16 (2 wn + j) + 4 (lane >> 4) + r
+    f32x4 acc8[PP ? 3 : 1][PP ? FMH : 1][2];
+    const int wm = wave >> 2, wn = wave & 3;
+    const int f0 = wm * FMH, nfr = wm == 0 ? FMH : FM - FMH;
 
     TileSrc<false, C::A_ROWS, BK, NW> srcA;
     TileSrc<TB, 128, BK, NW> srcW[3];
-    srcA.setup(p.A, p.lda, m0, M, wave, lane);
     const int n_total = MODE == MODE_WIDE ? p.n_total : PN;
+    if constexpr (!PP) {
+        srcA.setup(p.A, p.lda, m0, M, wave, lane);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, n_total, wave, lane);
+        for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, n_total, wave, lane);
+    }
     const int nt = p.K / BK;
+    // PP: LDS-DMA sources as uniform base (SGPRs) + per-lane 32-bit byte offset, as in gemm_dw8.h.  A image piece pc: rows
+    // (wave a + pc) 8 .. + 7 (clamped at M), 128 B each, 16-B chunk XOR (row & 7); W block piece pc: natural -- weight rows
+    // (wave 2 + pc) 8 .. + 7 of the block; transposed -- reduction rows (wave 2 + pc) 4 .. + 3, 256 B of the block's columns each
+    unsigned voffA[PP ? C::A_PPW : 1], voffW[2];
+    if constexpr (PP) {
+#pragma unroll
+        for (int pc = 0; pc < C::A_PPW; ++pc) {
+            const int rr = (wave * C::A_PPW + pc) * 8 + (lane >> 3);
+            int row = m0 + rr; row = row < M ? row : M - 1;
+            voffA[pc] = (unsigned)(((long)(row - m0) * p.lda + (((lane & 7) ^ (rr & 7)) << 3)) * 2);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            if constexpr (!TB) {
+                const int rr = (wave * 2 + pc) * 8 + (lane >> 3);
+                voffW[pc] = (unsigned)(((long)rr * p.ldw + (((lane & 7) ^ (rr & 7)) << 3)) * 2);
+            } else {
+                const int rr = (wave * 2 + pc) * 4 + (lane >> 4), s16 = lane & 15;
+                voffW[pc] = (unsigned)(((long)rr * p.ldw + ((((s16 >> 1) ^ swz_t(rr)) << 4) + (s16 & 1) * 8)) * 2);
+            }
+        }
+    }
+    const unsigned long long baseA = (unsigned long long)(p.A + (long)m0 * p.lda);
+    unsigned long long baseW = (unsigned long long)p.W;           // + the column block (MODE_WIDE)
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
     auto issue = [&](int t) {
         GV_LDS char* st = smem + (t & 1) * C::STAGE;
         const int k0 = t * BK;
@@ -112,6 +154,22 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) srcW[j].issue(p.ldw, k0, p.K, st + C::A_BYTES + j * C::W_BLOCK, wave);
     };
+    // ---- PP: pieces of a K-tile in DMA-stream order: A (a = A_PPW per wave), W0, W1, W2 (two per wave each); n = a + 6
+    constexpr int PA = C::A_PPW, PN_T = PA + 6;
+    auto issue_x = [&](auto Xc, int u) {
+        constexpr int X = decltype(Xc)::value;
+        const int uc = u < nt ? u : nt - 1;                   // tiles past the end re-read the last one: never consumed, keeps the counted waits uniform
+        const unsigned st = lds0 + (u & 1) * C::STAGE;
+        if constexpr (X < PA) {
+            glds16_s<0>(baseA + (unsigned long long)uc * (BK * 2), voffA[X], st + (wave * PA + X) * 1024);
+        } else {
+            constexpr int b = (X - PA) / 2, pc = (X - PA) % 2;
+            const unsigned dst = st + C::A_BYTES + b * C::W_BLOCK + (wave * 2 + pc) * 1024;
+            if constexpr (!TB) glds16_s<0>(baseW + ((unsigned long long)(128 * b) * p.ldw + (unsigned long long)uc * BK) * 2, voffW[pc], dst);
+            else glds16_s<b * 256>(baseW + (unsigned long long)uc * BK * p.ldw * 2, voffW[pc], dst);
+        }
+    };
+    if constexpr (PP) static_for<0, PN_T>([&](auto X) { issue_x(X, 0); }); else
     issue(0);
     // MODE_WIDE walks the 384-column blocks of the output with the same row panel: the A rows are staged again per block (from
     // L2), the block's first ring stage is requested before the previous block's epilogue (whose image lives in stage 1 and
@@ -123,11 +181,79 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) { s_dg[c][e] = 0.f; s_db[c][e] = 0.f; s_g[c][e] = 0.f; }
     for (int cb = 0; cb < ncb; ++cb) {
+    if constexpr (PP) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int i = 0; i < FMH; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc8[b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // prologue: tile 0 is out (start of the kernel / before the previous block's epilogue); A, W0, W1 of tile 1 follow
+        static_for<0, PA + 4>([&](auto X) { issue_x(X, 1); });
+        wait_vmcnt<PN_T + 2>();                               // A and W0 of tile 0 landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();            // the second half runs one barrier late
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 fa[2][FMH], fb[2][2];
+        // Phase (t, J), tile t in stage S = t & 1:
+        //   load segment:  fragment reads of THIS phase (J = 0: the tile's A fragments and W0's; J = 1, 2: W1's, W2's), LDS-DMA
+        //                  issue, counted vmcnt, lgkmcnt(0)   | s_barrier |   MFMA segment: 4 FMH MFMAs   | s_barrier
+        // (fragments are single-buffered: 144 accumulator registers leave no room for a second set).
+        // Stream position of piece (u, X) = n u + X (X: A 0 .. a-1, W0 a, a+1, W1 a+2, a+3, W2 a+4, a+5); issue: J = 0 -> W2 of
+        // t + 1, J = 1 -> A of t + 2, J = 2 -> W0, W1 of t + 2; P0 = 2 a + 10 pieces are out before phase (0, 0).
+        // RAW (staggered halves): an image read in load segment p was waited for in load segment p - 1 by its issuer:
+        //   (t, 0) retires W1(t): n + 2 pieces may fly; (t, 1) retires W2(t): n + a; (t, 2) retires A, W0 of t + 1: n + 2.
+        // WAR: the reads of a load segment are retired (lgkmcnt(0)) before its barrier, the image is restaged one phase
+        // later at the earliest (A: read (t, 0), restaged (t, 1); W0: (t, 0) / (t, 2); W1: (t, 1) / (t, 2); W2: (t, 2) / (t + 1, 0)).
+        auto phase = [&](auto Jc, auto Sc, int t) {
+            constexpr int J = decltype(Jc)::value, S = decltype(Sc)::value;
+            GV_LDS char* st = smem + S * C::STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[ks][j] = read_frag<TB, 128, BK>(st + C::A_BYTES + J * C::W_BLOCK, 2 * wn + j, ks, lane);
+            if constexpr (J == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < FMH; ++i) fa[ks][i] = read_frag<false, C::A_ROWS, BK>(st, f0 + i, ks, lane);
+                static_for<PA + 4, PN_T>([&](auto X) { issue_x(X, t + 1); }); wait_vmcnt<PN_T + 2>();
+            } else if constexpr (J == 1) { static_for<0, PA>([&](auto X) { issue_x(X, t + 2); }); wait_vmcnt<PN_T + PA>(); }
+            else { static_for<PA, PA + 4>([&](auto X) { issue_x(X, t + 2); }); wait_vmcnt<PN_T + 2>(); }
+            __builtin_amdgcn_s_waitcnt(0xC07F);               // this segment's reads are retired before its barrier
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            // (the wm = 1 half of an odd FM multiplies one row fragment past its own: staged rows, never stored -- keeps the
+            //  cluster branch-free and the two halves equally long)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < FMH; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc8[J][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc8[J][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        for (int t = 0; t < nt; t += 2) {                     // nt is even (K % 128 == 0)
+            phase(I0{}, I0{}, t); phase(I1{}, I0{}, t); phase(I2{}, I0{}, t);
+            phase(I0{}, I1{}, t + 1); phase(I1{}, I1{}, t + 1); phase(I2{}, I1{}, t + 1);
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();            // pair the late half's last barrier
+        wait_vmcnt<0>();
+    }
+    if constexpr (!PP) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nt; ++t) {
+    }
+    if constexpr (!PP) for (int t = 0; t < nt; ++t) {
         wait_vmcnt<0>();                      // my pieces of stage t have landed (nothing younger is in flight yet)
         __builtin_amdgcn_s_barrier();         // everybody's have; every wave is past its reads of stage t - 1
         if (t + 1 < nt) issue(t + 1);
@@ -153,20 +279,33 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     // of the LayerNorm stay inside a wave.  The global rows a pass needs (forward: the residual; backward: x and g, mean,
     // rstd) are all requested BEFORE the pass's image barrier, so their HBM latency overlaps the image traffic and the
     // other rows' arithmetic instead of being paid once per row.
-    constexpr int IB = MODE == MODE_WIDE ? C::ib_wide() : C::ib(NW == 8 ? (MODE == MODE_FWD ? 5 : 3) : (MODE == MODE_FWD ? 2 : 1));
+    // PP: a pass takes the SAME wave-relative row fragments [q0, q0 + IBH) of both halves (image row blocks h IBH + ii), so which
+    // accumulators a pass consumes is static and their registers are released pass by pass
+    constexpr int IBH = !PP ? 1 : (MODE == MODE_FWD ? (FMH < 2 ? FMH : 2) : 1);
+    constexpr int IB = PP ? 2 * IBH : (MODE == MODE_WIDE ? C::ib_wide() : C::ib(NW == 8 ? (MODE == MODE_FWD ? 5 : 3) : (MODE == MODE_FWD ? 2 : 1)));
+    static_assert(!PP || IB * 16 * IMG_STRIDE * 4 + (MODE == MODE_WIDE ? C::STAGE : 0) <= (MODE == MODE_WIDE ? C::LDS_WIDE : C::LDS), "PP image");
     constexpr int RPW = 16 * IB / NW;                             // rows per wave and pass
     GV_LDS float* img = (GV_LDS float*)(smem + (MODE == MODE_WIDE ? C::STAGE : 0));
     constexpr bool HAS_BIAS = MODE == MODE_FWD || (MODE == MODE_WIDE && EP >= EP_BIAS && EP <= EP_BIAS_GELU_SAVE);
-    f32x4 bias4[NF];
+    f32x4 bias4[NF], bias8[3][2];
     if constexpr (HAS_BIAS) {
 #pragma unroll
         for (int j = 0; j < NF; ++j)
             bias4[j] = p.bias ? *(const f32x4*)(p.bias + cb * PN + 16 * (NW * j + wave) + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bias8[b][j] = (PP && p.bias) ? *(const f32x4*)(p.bias + cb * PN + 128 * b + 16 * (2 * wn + j) + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if constexpr (MODE == MODE_WIDE) {
         if (cb + 1 < ncb) {                   // next block's weights; its first stage goes out now (stage 0 was last read at step nt - 2)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, (cb + 1) * PN + 128 * j, n_total, wave, lane);
+            for (int j = 0; j < 3; ++j) if constexpr (!PP) srcW[j].setup(p.W, p.ldw, (cb + 1) * PN + 128 * j, n_total, wave, lane);
+            if constexpr (PP) {
+                baseW = (unsigned long long)(TB ? p.W + (long)(cb + 1) * PN : p.W + (long)(cb + 1) * PN * p.ldw);
+                static_for<0, PN_T>([&](auto X) { issue_x(X, 0); });
+            } else
             issue(0);
         }
     }
@@ -182,17 +321,29 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         else { bt[c][0] = bt[c][1] = 0.f; }
     }
 
+    // rows of pass i0: image row r = wave + NW rr of the pass  ->  valid (compile-time per rr) and global row offset from m0
+    //   plain: row blocks i0 .. i0 + ni - 1 in order;   PP: slot = rr >> 1, half h = slot / IBH, fragment h FMH + i0 + slot % IBH
+    auto row_valid = [&](int i0, int ni, int rr) constexpr {
+        if (!PP) return rr < 16 * ni / NW;
+        const int slot = rr >> 1, h = slot / IBH, ii = slot % IBH;
+        return ii < ni && (h == 0 || i0 + ii < FM - FMH);
+    };
+    auto row_off = [&](int i0, int rr) constexpr {
+        if (!PP) return i0 * 16 + NW * rr;
+        const int slot = rr >> 1, h = slot / IBH, ii = slot % IBH;
+        return 16 * (h * FMH + i0 + ii) + 8 * (rr & 1);
+    };
 #pragma unroll
-    for (int i0 = 0; i0 < FM; i0 += IB) {
-        const int ni = (FM - i0) < IB ? (FM - i0) : IB;          // compile-time after unrolling
+    for (int i0 = 0; i0 < (PP ? FMH : FM); i0 += (PP ? IBH : IB)) {
+        const int ni = PP ? ((FMH - i0) < IBH ? (FMH - i0) : IBH) : ((FM - i0) < IB ? (FM - i0) : IB);          // compile-time after unrolling
         // ---- this wave's global rows of the pass (clamped at M: surplus rows load valid memory and are never stored)
         f32x2 pre_a[MODE == MODE_WIDE ? 1 : RPW][3], pre_b[MODE == MODE_BWD ? RPW : 1][3];
         float pre_mean[MODE == MODE_BWD ? RPW : 1], pre_rstd[MODE == MODE_BWD ? RPW : 1];
         bf16x2 pre_x[MODE == MODE_WIDE && EP == EP_DGELU ? RPW : 1][3];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            if (rr < 16 * ni / NW) {
-                int m = m0 + i0 * 16 + wave + NW * rr;
+            if (row_valid(i0, ni, rr)) {
+                int m = m0 + row_off(i0, rr) + wave;
                 m = m < M ? m : M - 1;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -211,6 +362,21 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         }
         if (i0 == 0) __syncthreads();                             // every wave is past the ring: it is image space now
         // ---- accumulators -> LDS image [rows of this pass][384 columns] f32
+        if constexpr (PP) {
+#pragma unroll
+            for (int i = 0; i < FMH; ++i) {
+                if (i >= i0 && i < i0 + ni && i < nfr) {          // static but for the last (a half's own fragment count)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4 v = acc8[b][i][j];
+                            if constexpr (HAS_BIAS) v += bias8[b][j];
+                            *(GV_LDS f32x4*)(img + ((wm * IBH + i - i0) * 16 + li16) * IMG_STRIDE + 128 * b + 16 * (2 * wn + j) + gq * 4) = v;
+                        }
+                }
+            }
+        } else {
 #pragma unroll
         for (int ii = 0; ii < IB; ++ii) {
             if (ii < ni) {
@@ -222,13 +388,14 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                 }
             }
         }
+        }
         __syncthreads();
         // ---- one wave per row
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            if (rr < 16 * ni / NW) {
+            if (row_valid(i0, ni, rr)) {
                 const int r = wave + NW * rr;
-                const int m = m0 + i0 * 16 + r;
+                const int m = m0 + row_off(i0, rr) + wave;
                 if (m < M) {                                      // wave-uniform
                     float v[3][2];
 #pragma unroll
@@ -341,9 +508,9 @@ int pick_fm(int M) {
     return 12;
 }
 
-template <int FM, int NW, int BK, bool TB, int MODE, int EP = 0>
+template <int FM, int NW, int BK, bool TB, int MODE, int EP = 0, int PP = 0>
 int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
-    auto kern = panel_kernel<FM, NW, BK, TB, MODE, EP>;
+    auto kern = panel_kernel<FM, NW, BK, TB, MODE, EP, PP>;
     using C = PC<FM, NW, BK>;
     constexpr int LDS_BYTES = MODE == MODE_WIDE ? C::LDS_WIDE : C::LDS;
     static bool attr_done = false;
@@ -353,7 +520,7 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
         attr_done = true;
     }
     static char kname[96] = "";
-    if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d, %d>", FM, NW, BK, TB ? "true" : "false", MODE, EP);   // as rocprofv3 prints it
+    if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d, %d, %d>", FM, NW, BK, TB ? "true" : "false", MODE, EP, PP);   // as rocprofv3 prints it
     const int grid = (p.M + C::BM - 1) / C::BM;
     // algorithmic bytes: forward  A row + f32 residual in + f32 row out + bf16 normalised row out + stats;
     // backward  dY row + f32 x row + f32 g in / out + bf16 g out; + the weight once
@@ -370,6 +537,16 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
 
 template <bool TB, int MODE, int EP = 0>
 int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
+    // the ping-pong k-loop walks K-tiles in pairs (static ring stage): K % 128 == 0; other depths keep the one-stage-ahead loop
+    if (p.K % 128 == 0) {
+        switch (pick_fm(p.M)) {
+            case 4: return launch_panel<4, 8, 64, TB, MODE, EP, 1>(p, s, name);
+            case 7: return launch_panel<7, 8, 64, TB, MODE, EP, 1>(p, s, name);
+            case 9: return launch_panel<9, 8, 64, TB, MODE, EP, 1>(p, s, name);
+            case 11: return launch_panel<11, 8, 64, TB, MODE, EP, 1>(p, s, name);
+            default: return launch_panel<12, 8, 64, TB, MODE, EP, 1>(p, s, name);
+        }
+    }
     switch (pick_fm(p.M)) {
         case 4: return launch_panel<4, 8, 64, TB, MODE, EP>(p, s, name);
         case 7: return launch_panel<7, 8, 64, TB, MODE, EP>(p, s, name);
