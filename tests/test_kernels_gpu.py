@@ -109,7 +109,7 @@ def test_linear_epilogues(dev):
     close(Cf, 0.25 * (A.float() @ B.float().t()), 1e-4, 1e-4, "alpha")
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 384, 128), (2500, 1152, 384), (4099, 1536, 384), (3000, 384, 1536)])
+@pytest.mark.parametrize("M,N,K", [(2048, 384, 128), (2500, 1152, 384), (4099, 1536, 384), (3000, 384, 1536), (47000, 768, 128), (33000, 384, 256)])
 def test_linear_wide_panel(dev, M, N, K):
     """gv_linear's wide bf16 products (M >= 2048, N % 384 == 0, K % 128 == 0, hot-path epilogues) run on the full-row kernel:
     exact on integer data (NT and NN forms, ragged last row panel), epilogues against fp32 torch, and identical to the
@@ -199,7 +199,7 @@ def test_linear_timing_rows(dev):
 
 
 # ------------------------------------------------------- full-row Linear + LayerNorm (panel kernel)
-@pytest.mark.parametrize("M,K", [(64, 64), (1380, 384), (44160, 1536), (25216, 384), (2000, 1152), (33000, 128), (1380, 192)])
+@pytest.mark.parametrize("M,K", [(64, 64), (1380, 384), (44160, 1536), (25216, 384), (2000, 1152), (33000, 128), (1380, 192), (47000, 384)])
 def test_linear_ln_fwd(dev, M, K):
     """gv_linear_ln_fwd: out = A W^T + bias + resid exactly (integer operands), and LayerNorm of the new row against
     F.layer_norm in fp32 (bf16 output tolerance); every supported rows-per-workgroup geometry (M picks FM = 4 .. 12)."""
@@ -231,7 +231,7 @@ def test_linear_ln_fwd(dev, M, K):
     close(y, torch.nn.functional.layer_norm(ref, (N,), gamma, beta, 1e-6), 8e-3, 8e-3, "ln out real")
 
 
-@pytest.mark.parametrize("M,K,g_init", [(64, 64, False), (1380, 1536, False), (44160, 1152, False), (25216, 1536, True), (3000, 384, False), (1380, 192, False)])
+@pytest.mark.parametrize("M,K,g_init", [(64, 64, False), (1380, 1536, False), (44160, 1152, False), (25216, 1536, True), (3000, 384, False), (1380, 192, False), (47000, 384, False), (33000, 1152, False)])
 def test_linear_ln_bwd(dev, M, K, g_init):
     """gv_linear_ln_bwd: dXn = dY W (W stored [K, N]) + the LayerNorm backward it feeds, against autograd in fp32."""
     o = ops()
