@@ -154,13 +154,16 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64, FwdCfg<NKT>::QT == 1 ? 2 : 1)
             mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
             mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
         }
+        float mxc[QT];                                    // exp2((s - mx) c) as one fma + exp2 per element
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mxc[qt] = -mx[qt] * c;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f((s[kt][qt][r] - mx[qt]) * c);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], c, mxc[qt]));
                     s[kt][qt][r] = p;
                     sum[qt] += p;
                 }
@@ -358,17 +361,19 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int q0 = qc * 32 + qt * 16 + 4 * g;
-                const f32x4 l4 = *(GV_LDS f32x4*)(lse + q0);
-                const f32x4 d4 = *(GV_LDS f32x4*)(delta + q0);
+                // per row, once for both key tiles: -lse * log2(e) and -delta * scale  (one fma / exp2 / select / fma / mul per element)
+                f32x4 l4 = *(GV_LDS f32x4*)(lse + q0), d4 = *(GV_LDS f32x4*)(delta + q0);
+                l4 *= -1.4426950408889634f;
+                d4 *= -a.scale;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     const bool kok = kb * 32 + kt * 16 + li < N;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool ok = kok && (q0 + r < N);
-                        const float p = ok ? __builtin_amdgcn_exp2f(s[qt][kt][r] * c - l4[r] * 1.4426950408889634f) : 0.f;
+                        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], c, l4[r])) : 0.f;
                         pv[qt][kt][r] = p;
-                        ds[qt][kt][r] = p * (dp[qt][kt][r] - d4[r]) * a.scale;
+                        ds[qt][kt][r] = p * fmaf(dp[qt][kt][r], a.scale, d4[r]);
                     }
                 }
             }
