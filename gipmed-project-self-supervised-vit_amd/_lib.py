@@ -35,7 +35,7 @@ gv_layernorm_fwd_args = _struct("gv_layernorm_fwd_args", [
 gv_layernorm_bwd_args = _struct("gv_layernorm_bwd_args", [
     ("dy", vp), ("x", vp), ("x_stride", i64), ("mean", vp), ("rstd", vp), ("gamma", vp),
     ("g", vp), ("g_stride", i64), ("gb", vp), ("gb_stride", i64), ("partials", vp),
-    ("rows", i32), ("D", i32), ("g_init", i32)])
+    ("rows", i32), ("D", i32), ("g_init", i32), ("gb_scale", vp)])
 gv_colsum_finalize_args = _struct("gv_colsum_finalize_args", [
     ("partials", vp), ("n_blocks", i32), ("n_which", i32), ("which", i32), ("C", i32), ("out", vp), ("accumulate", i32)])
 gv_ln_finalize_args = _struct("gv_ln_finalize_args", [
@@ -45,14 +45,15 @@ gv_colsum_args = _struct("gv_colsum_args", [
 gv_linear_args = _struct("gv_linear_args", [
     ("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldb", i64), ("ldc", i64),
     ("trans_a", i32), ("trans_b", i32), ("c_is_f32", i32), ("epilogue", i32), ("bias", vp),
-    ("resid", vp), ("ldr", i64), ("aux_in", vp), ("ld_aux", i64), ("aux_out", vp), ("pos", vp), ("P", i32), ("alpha", f32), ("colsum_a", vp), ("workspace", vp), ("workspace_bytes", i64)])
+    ("resid", vp), ("ldr", i64), ("aux_in", vp), ("ld_aux", i64), ("aux_out", vp), ("pos", vp), ("P", i32), ("alpha", f32), ("colsum_a", vp), ("workspace", vp), ("workspace_bytes", i64), ("row_scale", vp)])
 gv_linear_ln_fwd_args = _struct("gv_linear_ln_fwd_args", [
     ("A", vp), ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldw", i64), ("bias", vp), ("resid", vp), ("ldr", i64),
-    ("out", vp), ("ldo", i64), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp), ("mean", vp), ("rstd", vp)])
+    ("out", vp), ("ldo", i64), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp), ("mean", vp), ("rstd", vp), ("row_scale", vp)])
 gv_linear_ln_bwd_args = _struct("gv_linear_ln_bwd_args", [
     ("A", vp), ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldw", i64), ("x", vp), ("ldx", i64),
     ("mean", vp), ("rstd", vp), ("gamma", vp), ("g", vp), ("ldg", i64), ("gb", vp), ("ldgb", i64), ("partials", vp),
-    ("partial_blocks", i32), ("g_init", i32)])
+    ("partial_blocks", i32), ("g_init", i32), ("gb_scale", vp)])
+gv_expand_rows_args = _struct("gv_expand_rows_args", [("per_img", vp), ("row_img", vp), ("rows", vp), ("n_rep", i32), ("n_img", i32), ("T", i32)])
 GV_DW_GROUP_MAX = 4
 gv_dw_problem = _struct("gv_dw_problem", [("dY", vp), ("ldy", i64), ("X", vp), ("ldx", i64), ("dW", vp), ("ldw", i64), ("colsum_dy", vp),
                                           ("M", i32), ("N", i32)])
@@ -93,7 +94,7 @@ gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
 ENTRY_POINTS = {
     "gv_patchify": gv_patchify_args, "gv_crop_resize": gv_crop_resize_args, "gv_augment": gv_augment_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
     "gv_colsum_finalize": gv_colsum_finalize_args, "gv_ln_finalize": gv_ln_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
-    "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args, "gv_linear_dw_group": gv_linear_dw_group_args,
+    "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args, "gv_expand_rows": gv_expand_rows_args, "gv_linear_dw_group": gv_linear_dw_group_args,
     "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_cls_rows": gv_cls_rows_args,
     "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,

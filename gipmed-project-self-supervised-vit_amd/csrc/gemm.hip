@@ -354,6 +354,7 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     p.ksplit = 1; p.k_per_split = ((a->K + BK - 1) / BK) * BK;
     p.order = 0;
     p.colsum_a = a->colsum_a;
+    p.row_scale = a->row_scale;
     p.slab = nullptr;
     if (a->colsum_a) GV_REQUIRE(ta, GV_E_UNSUPPORTED, "gv_linear: colsum_a needs trans_a (it sums the dW product's A operand)");
     hipStream_t s = (hipStream_t)stream;
@@ -509,7 +510,7 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
         p.epi = GV_EPI_ACCUM; p.bias = nullptr; p.resid = nullptr; p.ldr = 0; p.aux_in = nullptr; p.ld_aux = 0; p.aux_out = nullptr;
         p.pos = nullptr; p.P = 0; p.alpha = 1.f;
         p.tiles_m = (pr.M + BM - 1) / BM; p.tiles_n = (pr.N + BN - 1) / BN;
-        p.order = 0; p.colsum_a = pr.colsum_dy;
+        p.order = 0; p.colsum_a = pr.colsum_dy; p.row_scale = nullptr;
         G.tile_base[q] = tiles;
         tiles += p.tiles_m * p.tiles_n;
     }

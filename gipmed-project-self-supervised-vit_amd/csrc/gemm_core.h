@@ -28,6 +28,7 @@ struct GemmP {
     int tiles_m, tiles_n, ksplit, k_per_split;
     float* slab;       // split-K: non-null -> partial tiles are stored here [slice][M][N] instead of atomics
     float* colsum_a;   // TA only: += column sums of A (bias gradient), computed as MFMAs against ones
+    const float* row_scale;   // RESID only: v *= row_scale[m] before the residual add (stochastic depth); null = 1
     int order;   // 0: flat m-major items; 1: per-XCD M-panel ranges walked n-major (L2 reuse of A)
 };
 
@@ -619,6 +620,11 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
 #pragma unroll
                                 for (int q = 0; q < W; ++q) v[q] *= dgelu_f((float)a[q]);
                             }
+                            if ((epi & GV_EPI_RESID) && g.row_scale) {
+                                const float rs = g.row_scale[mc];
+#pragma unroll
+                                for (int q = 0; q < W; ++q) v[q] *= rs;
+                            }
 #pragma unroll
                             for (int q = 0; q < W; q += 4) {
                                 f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -660,7 +666,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
                         if (e2 & GV_EPI_SAVE_PRE) g.aux_out[orow * g.ld_aux + n + r] = (bf16)x;
                         if (e2 & GV_EPI_GELU) x = gelu_f(x);
                         if (e2 & GV_EPI_DGELU) x *= dgelu_f((float)g.aux_in[orow * g.ld_aux + n + r]);
-                        if (e2 & GV_EPI_RESID) x += g.resid[orow * g.ldr + n + r];
+                        if (e2 & GV_EPI_RESID) x = (g.row_scale ? x * g.row_scale[m] : x) + g.resid[orow * g.ldr + n + r];
                         if (e2 & GV_EPI_POS) x += g.pos[(long)prow * N + n + r];
                         OutT* dst = Cp + orow * g.ldc + n + r;
                         if constexpr (sizeof(OutT) == 4) { if (e2 & GV_EPI_ACCUM) x += *dst; }

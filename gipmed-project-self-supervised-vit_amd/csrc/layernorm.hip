@@ -135,16 +135,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(gv_layernorm_bwd_args a) {
         }
         c1 = wave_sum(c1) * (1.0f / D);
         c2 = wave_sum(c2) * (1.0f / D);
+        // stochastic depth: the gradient that enters the branch in front of this residual add (and that branch's bias
+        // gradient, the third column sum) carries the branch's per-row factor; the residual-stream gradient g does not
+        const float gs = a.gb_scale ? a.gb_scale[row] : 1.0f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int c = (i * 64 + lane) * VEC;
+            float gbv[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 gv[i][j] += rstd * (wdy[i][j] - c1 - xh[i][j] * c2);
-                s_g[i][j] += gv[i][j];
+                gbv[j] = gv[i][j] * gs;
+                s_g[i][j] += gbv[j];
             }
             stf<VEC>(g + c, gv[i]);
-            if (a.gb) stb<VEC>((bf16*)a.gb + (long)row * a.gb_stride + c, gv[i]);
+            if (a.gb) stb<VEC>((bf16*)a.gb + (long)row * a.gb_stride + c, gbv);
         }
     }
     // block reduce of the three column sums -> partials[block][3][D]

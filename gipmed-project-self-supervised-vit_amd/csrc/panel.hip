@@ -81,6 +81,9 @@ struct PanelP {
     const float* gamma; const float* beta; float eps; bf16* y; float* mean; float* rstd;
     // backward
     const float* x; long ldx; float* g; long ldg; bf16* gb; long ldgb; float* partials; int g_init;
+    // stochastic depth: forward out = resid + row_scale[m] (A W^T + bias); backward gb = bf16(g gb_scale[m]) (and the third
+    // column sum, the bias gradient of the branch in front of the residual add, sums the scaled rows)
+    const float* row_scale; const float* gb_scale;
     // wide (plain Linear with N = ncb x 384 output columns, bf16 out): out = epilogue(A W^T) one 384-column block after the other
     bf16* outb; long ldob; const bf16* aux_in; bf16* aux_out; long ld_aux; int ncb, n_total;
 };
@@ -415,9 +418,10 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                         }
                     } else if constexpr (MODE == MODE_FWD) {
                         float* orow = p.out + (long)m * p.ldo;
+                        const float rs = p.row_scale ? p.row_scale[m] : 1.0f;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            v[c][0] += pre_a[rr][c][0]; v[c][1] += pre_a[rr][c][1];
+                            v[c][0] = fmaf(v[c][0], rs, pre_a[rr][c][0]); v[c][1] = fmaf(v[c][1], rs, pre_a[rr][c][1]);
                             *(f32x2*)(orow + (c * 64 + lane) * 2) = f32x2{v[c][0], v[c][1]};
                         }
                         if (ln) {
@@ -456,16 +460,19 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                             }
                         c1 = wave_sum_dpp(c1) * (1.0f / PN);
                         c2 = wave_sum_dpp(c2) * (1.0f / PN);
+                        const float gs = p.gb_scale ? p.gb_scale[m] : 1.0f;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const int col = (c * 64 + lane) * 2;
+                            float gbv[2];
 #pragma unroll
                             for (int e = 0; e < 2; ++e) {
                                 gv[c][e] += rstd * (wdy[c][e] - c1 - xh[c][e] * c2);
-                                s_g[c][e] += gv[c][e];
+                                gbv[e] = gv[c][e] * gs;
+                                s_g[c][e] += gbv[e];
                             }
                             *(f32x2*)(grow + col) = f32x2{gv[c][0], gv[c][1]};
-                            if (p.gb) *(bf16x2*)(p.gb + (long)m * p.ldgb + col) = bf16x2{(bf16)gv[c][0], (bf16)gv[c][1]};
+                            if (p.gb) *(bf16x2*)(p.gb + (long)m * p.ldgb + col) = bf16x2{(bf16)gbv[0], (bf16)gbv[1]};
                         }
                     }
                 }
@@ -599,6 +606,7 @@ extern "C" int gv_linear_ln_fwd(const gv_linear_ln_fwd_args* a, void* stream) {
     p.A = (const bf16*)a->A; p.W = (const bf16*)a->W; p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw;
     p.bias = a->bias; p.resid = a->resid; p.ldr = a->ldr; p.out = a->out; p.ldo = a->ldo;
     p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps; p.y = (bf16*)a->y; p.mean = a->mean; p.rstd = a->rstd;
+    p.row_scale = a->row_scale;
     return dispatch_fm<false, MODE_FWD>(p, (hipStream_t)stream, "gv_linear_ln_fwd");
 }
 
@@ -615,5 +623,6 @@ extern "C" int gv_linear_ln_bwd(const gv_linear_ln_bwd_args* a, void* stream) {
     p.A = (const bf16*)a->A; p.W = (const bf16*)a->W; p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw;
     p.x = a->x; p.ldx = a->ldx; p.mean = (float*)a->mean; p.rstd = (float*)a->rstd; p.gamma = a->gamma;
     p.g = a->g; p.ldg = a->ldg; p.gb = (bf16*)a->gb; p.ldgb = a->ldgb; p.partials = a->partials; p.g_init = a->g_init;
+    p.gb_scale = a->gb_scale;
     return dispatch_fm<true, MODE_BWD>(p, (hipStream_t)stream, "gv_linear_ln_bwd");
 }

@@ -285,6 +285,22 @@ extern "C" int gv_store_f32(const gv_store_f32_args* a, void* stream) {
     return GV_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void expand_rows_kernel(gv_expand_rows_args a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)a.n_rep * a.T) { const long r = i / a.T; a.rows[i] = a.per_img[r * a.n_img + a.row_img[i - r * a.T]]; }
+}
+}  // namespace
+
+extern "C" int gv_expand_rows(const gv_expand_rows_args* a, void* stream) {
+    GV_REQUIRE(a && a->per_img && a->row_img && a->rows, GV_E_NULL, "gv_expand_rows: null pointer");
+    GV_REQUIRE(a->n_rep > 0 && a->n_img > 0 && a->T > 0, GV_E_SHAPE, "gv_expand_rows: bad shape");
+    const long n = (long)a->n_rep * a->T;
+    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_expand_rows");
+    return GV_OK;
+}
+
 extern "C" int gv_gather_cls(const gv_gather_cls_args* a, void* stream) {
     GV_REQUIRE(a && a->x && a->y, GV_E_NULL, "gv_gather_cls: null pointer");
     GV_REQUIRE(a->n_img > 0 && a->N > 0 && a->D > 0, GV_E_SHAPE, "gv_gather_cls: bad shape");

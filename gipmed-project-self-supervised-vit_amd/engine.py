@@ -237,6 +237,27 @@ class VitGroup:
             self.gb3, self.gb4 = e((T, D), bf16), e((T, D), bf16)
             self.dh_b, self.dqkv_b = e((T, 4 * D), bf16), e((T, 3 * D), bf16)
 
+        self.depth, self.device = depth, device
+        self.rs = None            # stochastic depth: f32 [depth, 2, T] row factors of the attention / MLP branch (set_drop)
+        self.drop_img = None      # ... and the per-image factors they were expanded from
+        self._row_img = None
+
+    def set_drop(self, per_img: Optional[torch.Tensor]):
+        """Stochastic depth (timm DropPath, vit.pyc@L66-74) for the next forward / backward of this group: ``per_img`` f32
+        [depth, 2, n_img] on the device = keep / (1 - p) per image for each block's attention and MLP branch (images in
+        segment order), or None to switch it off.  Expanded to one factor per token row in one launch."""
+        self.drop_img = per_img
+        if per_img is None:
+            self.rs = None
+            return
+        assert per_img.dtype == f32 and tuple(per_img.shape) == (self.depth, 2, self.n_img), (per_img.shape, (self.depth, 2, self.n_img))
+        if self._row_img is None:
+            m = torch.cat([sg.img0 + torch.arange(sg.T, dtype=torch.int32) // sg.N for sg in self.segs])
+            self._row_img = m.to(self.device)
+            self._rs_buf = _empty((self.depth, 2, self.T), f32, self.device)
+        ops.expand_rows(per_img.contiguous(), self._row_img, self._rs_buf, self.depth * 2, self.n_img, self.T)
+        self.rs = self._rs_buf
+
     def xbuf(self, j):
         return self.x[j] if self.save else self.x[j % 3]
 
@@ -298,6 +319,7 @@ class VitRunner:
             b, s = f"blocks.{i}.", G.slot(i)
             xa, xb, xc = G.xbuf(2 * i), G.xbuf(2 * i + 1), G.xbuf(2 * i + 2)
             st = G.stats[s]
+            rs_a, rs_m = (G.rs[i, 0], G.rs[i, 1]) if G.rs is not None else (None, None)      # stochastic depth of the two branches
             if not fused or i == 0:
                 ops.layernorm_fwd(xa, W.f(b + "norm1.weight"), W.f(b + "norm1.bias"), T, D, y=G.xn1[s], mean=st[0], rstd=st[1])
             ops.linear(G.xn1[s], W.w(b + "attn.qkv.weight"), G.qkv[s], T, 3 * D, D, epilogue=E.EPI_BIAS, bias=W.f(b + "attn.qkv.bias"))
@@ -305,10 +327,10 @@ class VitRunner:
                 ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s])
             if fused:
                 ops.linear_ln_fwd(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, bias=W.f(b + "attn.proj.bias"), resid=xa,
-                                  gamma=W.f(b + "norm2.weight"), beta=W.f(b + "norm2.bias"), y=G.xn2[s], mean=st[2], rstd=st[3])
+                                  gamma=W.f(b + "norm2.weight"), beta=W.f(b + "norm2.bias"), y=G.xn2[s], mean=st[2], rstd=st[3], row_scale=rs_a)
             else:
                 ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
-                           bias=W.f(b + "attn.proj.bias"), resid=xa)
+                           bias=W.f(b + "attn.proj.bias"), resid=xa, row_scale=rs_a)
                 ops.layernorm_fwd(xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), T, D, y=G.xn2[s], mean=st[2], rstd=st[3])
             ops.linear(G.xn2[s], W.w(b + "mlp.fc1.weight"), G.h[s], T, 4 * D, D,
                        epilogue=E.EPI_BIAS | E.EPI_GELU | (E.EPI_SAVE_PRE if G.save else 0),   # a forward-only group keeps no pre-activation
@@ -318,10 +340,11 @@ class VitRunner:
                 nb, ns = f"blocks.{i + 1}.", G.slot(i + 1)
                 ops.linear_ln_fwd(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, 4 * D, bias=W.f(b + "mlp.fc2.bias"), resid=xb,
                                   gamma=W.f(nb + "norm1.weight") if nxt else None, beta=W.f(nb + "norm1.bias") if nxt else None,
-                                  y=G.xn1[ns] if nxt else None, mean=G.stats[ns][0] if nxt else None, rstd=G.stats[ns][1] if nxt else None)
+                                  y=G.xn1[ns] if nxt else None, mean=G.stats[ns][0] if nxt else None, rstd=G.stats[ns][1] if nxt else None,
+                                  row_scale=rs_m)
             else:
                 ops.linear(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
-                           bias=W.f(b + "mlp.fc2.bias"), resid=xb)
+                           bias=W.f(b + "mlp.fc2.bias"), resid=xb, row_scale=rs_m)
         xl = G.xbuf(2 * self.depth)
         for sg in G.segs:
             r0 = row_off + sg.img0
@@ -343,9 +366,13 @@ class VitRunner:
         gb_first = sets[(self.depth - 1) & 1][0] if grouped else G.gb
         G.g.zero_(); gb_first.zero_()
         xl = G.x[2 * self.depth]
+        # stochastic depth: the bf16 gradient handed to a branch carries that branch's row factor (rs[i, 0] attention, rs[i, 1] MLP)
+        rs = G.rs
         for sg in G.segs:
+            # (the final norm touches the CLS rows only, one per image: the per-image factors are its row factors)
             ops.layernorm_bwd(dfeat[sg.img0:sg.img0 + sg.n_img], sg.rows(xl), sg.fstats[0], sg.fstats[1], W.f("norm.weight"), sg.rows(G.g),
-                              sg.rows(gb_first), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True)
+                              sg.rows(gb_first), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True,
+                              gb_scale=None if rs is None else G.drop_img[self.depth - 1, 1, sg.img0:sg.img0 + sg.n_img])
             self._fin3(W.g("norm.weight"), W.g("norm.bias"), W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
         # The weight-gradient GEMMs are off the critical path (nothing in backward consumes dW):
         # they run on a side stream beside the dX chain, so their tiles fill the tail of every
@@ -383,18 +410,18 @@ class VitRunner:
         # partials buffers rotate; one is rewritten only after the finalize that read it (three calls ago) has run.
         ring, fin_ev, ring_i, last_side = self.partials_ring, [None, None, None], [0], [None]
 
-        def ln_bwd(dy, x, mean, rstd, gamma, gb, d0, d1, d2, dx_of=None):
+        def ln_bwd(dy, x, mean, rstd, gamma, gb, d0, d1, d2, dx_of=None, gb_scale=None):
             """LayerNorm backward into the residual gradient.  ``dx_of = (dY, W, K)``: the dX product that produces ``dy``
             runs fused with it (gv_linear_ln_bwd) and ``dy`` never exists in HBM."""
             k = ring_i[0]
             ring_i[0] = (k + 1) % 3
             join(fin_ev[k])
             if dx_of is not None and self.fused:
-                nblk = ops.linear_ln_bwd(dx_of[0], dx_of[1], x, mean, rstd, gamma, G.g, gb, ring[k], T, dx_of[2])
+                nblk = ops.linear_ln_bwd(dx_of[0], dx_of[1], x, mean, rstd, gamma, G.g, gb, ring[k], T, dx_of[2], gb_scale=gb_scale)
             else:
                 if dx_of is not None:
                     ops.linear(dx_of[0], dx_of[1], dy, T, D, dx_of[2], trans_b=True)
-                ops.layernorm_bwd(dy, x, mean, rstd, gamma, G.g, gb, ring[k], T, D)
+                ops.layernorm_bwd(dy, x, mean, rstd, gamma, G.g, gb, ring[k], T, D, gb_scale=gb_scale)
                 nblk = L.LN_PARTIAL_BLOCKS
             if side is None:
                 ops.ln_finalize(ring[k], nblk, D, d0, d1, d2)
@@ -436,14 +463,14 @@ class VitRunner:
             ops.linear(gb_mlp, W.w(b + "mlp.fc2.weight"), dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
             ln_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), gb_att,
                    W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"),
-                   dx_of=(dh, W.w(b + "mlp.fc1.weight"), 4 * D))
+                   dx_of=(dh, W.w(b + "mlp.fc1.weight"), 4 * D), gb_scale=None if rs is None else rs[i, 0])
             ops.linear(gb_att, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             for sg in G.segs:
                 ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(dqkv))
             join(done_grp[par ^ 1])                       # block i + 1's group read gb_next (its MLP-half dY)
             ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
                    W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
-                   dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D))
+                   dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])
             probs = [(gb_mlp, G.h[i], W.g(b + "mlp.fc2.weight"), None),
                      (dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), W.g(b + "mlp.fc1.bias")),
                      (gb_att, G.o[i], W.g(b + "attn.proj.weight"), None),
@@ -464,7 +491,7 @@ class VitRunner:
             join(done_proj)              # last block's dW_proj read gb2
             ln_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), gbs[1],
                    W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"),
-                   dx_of=(G.dh, W.w(b + "mlp.fc1.weight"), 4 * D))
+                   dx_of=(G.dh, W.w(b + "mlp.fc1.weight"), 4 * D), gb_scale=None if rs is None else rs[i, 0])
             # attention
             ops.linear(gbs[1], W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             done_proj = dw(gbs[1], G.o[i], W.g(b + "attn.proj.weight"), D, D)
@@ -475,7 +502,7 @@ class VitRunner:
             join(done_fc2)               # this block's dW_fc2 read gb
             ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gbs[0],
                    W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
-                   dx_of=(G.dqkv, W.w(b + "attn.qkv.weight"), 3 * D))
+                   dx_of=(G.dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])
             report(i)
         join(done_qkv)          # every dW product is in (the side stream runs them in order); ws is free again
         join(last_side[0])      # ... and the last finalize
@@ -679,6 +706,11 @@ class DinoEngine:
         return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
 
     # ---- the step --------------------------------------------------------------------
+    def set_drop_path(self, per_img: Optional[torch.Tensor]):
+        """Stochastic depth for the STUDENT's next steps (the teacher runs without, as in DINO): f32 [depth, 2, V * B] on the
+        device, keep / (1 - p) per crop image (global crops first, crop-major like the feature rows), or None."""
+        self.g_stu.set_drop(per_img)
+
     def set_hyper(self, lr=None, wd=None, momentum_teacher=None, teacher_temp=None, n_micro: int = 1):
         """Put the per-step schedule values into the device hyper vector with a tiny stream-ordered
         kernel whose ARGUMENTS carry them.  Not a memcpy: the host runs several steps ahead of the
@@ -884,6 +916,11 @@ class SupervisedEngine:
 
     def state_dict(self, ema: bool = False):
         return self.arena.state_dict(self.arena.t if ema else None)
+
+    def set_drop_path(self, per_img: Optional[torch.Tensor]):
+        """Stochastic depth (--drop-path) for the next training steps: f32 [depth, 2, batch] on the device = keep / (1 - p)
+        per image and residual branch, or None (evaluation: ``forward`` with it set would scale the branches too)."""
+        self.grp.set_drop(per_img)
 
     def grads(self):
         return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}

@@ -219,19 +219,26 @@ def create_model(model_name: str, pretrained: bool = False, in_chans: int = 3, n
                  drop_rate: float = 0.0, drop_path_rate: Optional[float] = None, checkpoint_path: str = "",
                  img_size: int = 256, batch: int = 8, device: str = "cuda:0", seed: int = 0, **engine_kwargs) -> VitModel:
     """Counterpart of ``timm.create_model`` as the reference calls it (train.py:482-495) for the ViT names it documents.
-    Unsupported requests fail here instead of being ignored: other channel counts, dropout / stochastic depth (not built),
+    Unsupported requests fail here instead of being ignored: other channel counts, dropout (not built; stochastic depth is),
     ``pretrained`` without a checkpoint file (there is no network).  ``num_classes=None`` keeps the checkpoint-less default
     of the reference's runs (2 classes, train_instruct.txt:16-34)."""
     from .engine import SupervisedEngine
     arch = resolve_arch(model_name)
     if in_chans != 3:
         raise ValueError(f"create_model: in_chans={in_chans}; the hot path is built for RGB tiles")
-    if drop_rate or drop_path_rate:
-        raise ValueError("create_model: dropout / drop-path are not built (DESIGN.md section 6)")
+    if drop_rate:
+        raise ValueError("create_model: dropout (drop_rate) is not built (DESIGN.md section 6); stochastic depth (drop_path_rate) is")
     if pretrained and not checkpoint_path:
         raise ValueError("create_model: pretrained=True needs checkpoint_path (no network on this system)")
     C = 2 if num_classes is None else int(num_classes)
     eng = SupervisedEngine(arch=arch, img_size=img_size, num_classes=C, batch=batch, device=device, **engine_kwargs)
     state = load_encoder_checkpoint(checkpoint_path, arch, img_size, C) if checkpoint_path else init_vit_state(arch, img_size, C, seed=seed)
     eng.load_state(state)
-    return VitModel(eng, arch)
+    model = VitModel(eng, arch)
+    # stochastic depth: the training loop hands the next step's draws to the engine -- engine.set_drop_path(model.drop_path.sample())
+    model.drop_path_rate = float(drop_path_rate or 0.0)
+    model.drop_path = None
+    if model.drop_path_rate:
+        from .droppath import DropPathSampler
+        model.drop_path = DropPathSampler(ARCHS[arch]["depth"], batch, model.drop_path_rate, seed, device)
+    return model

@@ -97,10 +97,11 @@ def layernorm_fwd(x, gamma, beta, rows: int, D: int, x_stride: Optional[int] = N
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, g, gb, partials, rows: int, D: int, x_stride=None, g_stride=None,
-                  gb_stride=None, g_init: bool = False):
+                  gb_stride=None, g_init: bool = False, gb_scale=None):
+    """``gb_scale`` f32 [rows]: gb = bf16(g * gb_scale[row]) (stochastic depth of the branch in front of this residual add)."""
     a = L.gv_layernorm_bwd_args(dy.data_ptr(), x.data_ptr(), D if x_stride is None else x_stride, mean.data_ptr(),
                                 rstd.data_ptr(), gamma.data_ptr(), g.data_ptr(), D if g_stride is None else g_stride,
-                                _p(gb), D if gb_stride is None else gb_stride, partials.data_ptr(), rows, D, int(g_init))
+                                _p(gb), D if gb_stride is None else gb_stride, partials.data_ptr(), rows, D, int(g_init), _p(gb_scale))
     L.call("gv_layernorm_bwd", a, _stream())
 
 
@@ -122,7 +123,7 @@ def colsum(x, rows: int, C: int, workspace, out, accumulate: bool = False, ld: O
 
 def linear(A, B, C, M: int, N: int, K: int, *, trans_a=False, trans_b=False, epilogue=0, bias=None, resid=None,
            aux_in=None, aux_out=None, pos=None, P=0, alpha=1.0, lda=None, ldb=None, ldc=None, ldr=None, ld_aux=None,
-           colsum_a=None, workspace=None):
+           colsum_a=None, workspace=None, row_scale=None):
     """C[M,N] = op(A) op(B) (+ epilogue); see include/gipvit.h gv_linear."""
     a = L.gv_linear_args()
     a.A, a.B, a.C, a.M, a.N, a.K = A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K
@@ -132,7 +133,7 @@ def linear(A, B, C, M: int, N: int, K: int, *, trans_a=False, trans_b=False, epi
     a.trans_a, a.trans_b, a.c_is_f32, a.epilogue = int(trans_a), int(trans_b), int(C.dtype == f32), epilogue
     a.bias, a.resid, a.ldr = _p(bias), _p(resid), (N if ldr is None else ldr)
     a.aux_in, a.ld_aux, a.aux_out = _p(aux_in), (N if ld_aux is None else ld_aux), _p(aux_out)
-    a.pos, a.P, a.alpha, a.colsum_a = _p(pos), P, alpha, _p(colsum_a)
+    a.pos, a.P, a.alpha, a.colsum_a, a.row_scale = _p(pos), P, alpha, _p(colsum_a), _p(row_scale)
     if workspace is not None:
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     L.call("gv_linear", a, _stream())
@@ -156,18 +157,18 @@ def linear_timing_read():
 
 
 def linear_ln_fwd(A, W, out, M: int, K: int, *, bias=None, resid=None, gamma=None, beta=None, y=None, mean=None, rstd=None, eps: float = 1e-6,
-                  N: int = 384):
+                  N: int = 384, row_scale=None):
     """out = A W^T + bias + resid (f32) and, with gamma, y / mean / rstd = LayerNorm of the new row; see gv_linear_ln_fwd."""
     a = L.gv_linear_ln_fwd_args(A.data_ptr(), W.data_ptr(), M, N, K, K, K, _p(bias), _p(resid), N, out.data_ptr(), N,
-                                _p(gamma), _p(beta), eps, _p(y), _p(mean), _p(rstd))
+                                _p(gamma), _p(beta), eps, _p(y), _p(mean), _p(rstd), _p(row_scale))
     L.call("gv_linear_ln_fwd", a, _stream())
 
 
-def linear_ln_bwd(dY, W, x, mean, rstd, gamma, g, gb, partials, M: int, K: int, *, g_init: bool = False, N: int = 384) -> int:
+def linear_ln_bwd(dY, W, x, mean, rstd, gamma, g, gb, partials, M: int, K: int, *, g_init: bool = False, N: int = 384, gb_scale=None) -> int:
     """dXn = dY W (W stored [K, N]) fused with the LayerNorm backward it feeds; returns the number of partial blocks
     written (the n_blocks argument of ln_finalize); see gv_linear_ln_bwd."""
     a = L.gv_linear_ln_bwd_args(dY.data_ptr(), W.data_ptr(), M, N, K, K, N, x.data_ptr(), N, mean.data_ptr(), rstd.data_ptr(),
-                                gamma.data_ptr(), g.data_ptr(), N, _p(gb), N, partials.data_ptr(), partials.shape[0], int(g_init))
+                                gamma.data_ptr(), g.data_ptr(), N, _p(gb), N, partials.data_ptr(), partials.shape[0], int(g_init), _p(gb_scale))
     L.call("gv_linear_ln_bwd", a, _stream())
     return L.lib.gv_linear_ln_blocks(M)
 
@@ -199,6 +200,11 @@ def attention_bwd(qkv, o, d_o, lse, n_img: int, N: int, H: int, scale: float, dq
     a = L.gv_attention_bwd_args(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), n_img, N, H, scale)
     L.call("gv_attention_bwd", a, _stream())
     return dqkv
+
+
+def expand_rows(per_img, row_img, rows, n_rep: int, n_img: int, T: int):
+    """rows[r, t] = per_img[r, row_img[t]]: per-image stochastic-depth factors -> one factor per token row (n_rep branches)."""
+    L.call("gv_expand_rows", L.gv_expand_rows_args(per_img.data_ptr(), row_img.data_ptr(), rows.data_ptr(), n_rep, n_img, T), _stream())
 
 
 def cls_rows(x, cls, pos, n_img: int, N: int, D: int):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 4
+#define GV_ABI_VERSION 5
 enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
        GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
@@ -137,6 +137,8 @@ typedef struct {
     float* partials;
     int32_t rows, D;
     int32_t g_init;       /* 1: g is treated as 0 on input (g = dx)          */
+    const float* gb_scale; /* optional [rows]: gb[r] = bf16(g[r] * gb_scale[r]) -- the gradient entering a branch whose
+                            * output was scaled by stochastic depth; NULL = 1  */
 } gv_layernorm_bwd_args;
 int gv_layernorm_bwd(const gv_layernorm_bwd_args* a, void* stream);
 
@@ -202,6 +204,9 @@ typedef struct {
      * meeting in C through f32 atomics (the atomic volume is ~33 MB per launch at full occupancy
      * and runs at ~1.3 TB/s; slab stores + reduce move the same bytes at HBM speed).           */
     float* workspace; int64_t workspace_bytes;
+    /* RESID only, optional: v *= row_scale[m] before the residual add -- stochastic depth (timm DropPath, train.py:283-288
+     * --drop-path: keep / (1 - p) of the token's image, see gv_expand_rows); NULL = 1                                  */
+    const float* row_scale;
 } gv_linear_args;
 /* upper bound of the split-K scratch gv_linear can use for any shape: 64 MiB */
 int64_t gv_linear_workspace_bytes(void);
@@ -261,6 +266,7 @@ typedef struct {
     const float* gamma; const float* beta; float eps;
     void* y;                             /* bf16 [M, N] compact                             */
     float* mean; float* rstd;            /* [M]                                             */
+    const float* row_scale;              /* optional [M]: out = resid + row_scale[m] * (A W^T + bias) (stochastic depth)    */
 } gv_linear_ln_fwd_args;
 int gv_linear_ln_fwd(const gv_linear_ln_fwd_args* a, void* stream);
 
@@ -280,10 +286,17 @@ typedef struct {
     void* gb; int64_t ldgb;              /* bf16 out (may be NULL)                          */
     float* partials; int32_t partial_blocks;
     int32_t g_init;                      /* 1: g is treated as 0 on input                   */
+    const float* gb_scale;               /* optional [M]: gb[m,:] = bf16(g[m,:] * gb_scale[m]) (stochastic depth)           */
 } gv_linear_ln_bwd_args;
 int gv_linear_ln_bwd(const gv_linear_ln_bwd_args* a, void* stream);
 /* workgroups (= partial blocks) a gv_linear_ln_* launch over M rows uses */
 int gv_linear_ln_blocks(int32_t M);
+
+/* ---- stochastic depth (timm DropPath behind --drop-path, train.py:283-288; vit.pyc@L66-74): n_rep sets of per-image
+ * factors keep / (1 - p) (one set per residual branch) expanded to one factor per token row of a multi-crop row space:
+ * rows[r*T + t] = per_img[r*n_img + row_img[t]],  row_img[t] = the image token row t belongs to.                   */
+typedef struct { const float* per_img; const int32_t* row_img; float* rows; int32_t n_rep, n_img, T; } gv_expand_rows_args;
+int gv_expand_rows(const gv_expand_rows_args* a, void* stream);
 
 /* ---- attention (vit.pyc@L119-131): softmax(q k^T * scale) v per (image, head)
  * on packed qkv bf16 [n_img*N, 3, H, 64] -> o bf16 [n_img*N, H, 64];

@@ -52,24 +52,26 @@ class DinoOracle:
     def crops(self, tiles_u8):
         return [vo.normalize_window(tiles_u8, w, dtype=self.dtype) for w in self.wins]
 
-    def forward_backward(self, tiles_u8, teacher_temp=None):
+    def forward_backward(self, tiles_u8, teacher_temp=None, drop=None):
+        """``drop``: stochastic-depth factors of the STUDENT pass, [depth, 2, V * B] in crop order (vo.drop_path_factors); the
+        teacher runs without (DINO: teacher in eval mode)."""
         crops = self.crops(tiles_u8)
         V, G = len(crops), self.n_global
         with torch.no_grad():
             t_out = vo.multicrop_forward(self.tp, self.thp, crops[:G], self.arch)
         sp, shp = _leafify(self.p), _leafify(self.hp)
-        s_out = vo.multicrop_forward(sp, shp, crops, self.arch)
+        s_out = vo.multicrop_forward(sp, shp, crops, self.arch, drop=drop)
         loss, bsum = vo.dino_loss(s_out, t_out, self.center, V, G, self.ts, self.tt if teacher_temp is None else teacher_temp)
         loss.backward()
         grads = {**{"backbone." + k: v.grad for k, v in sp.items()},
                  **{"head." + k: v.grad for k, v in shp.items()}}
         return loss.detach(), grads, s_out.detach(), t_out, bsum
 
-    def step(self, tiles_u8, lr=None, wd=None, momentum_teacher=None, teacher_temp=None, train_last_layer=True):
+    def step(self, tiles_u8, lr=None, wd=None, momentum_teacher=None, teacher_temp=None, train_last_layer=True, drop=None):
         """One DINO step with this step's schedule values (cosine wd / teacher momentum, teacher-temperature
         warm-up, last layer frozen during the first epochs).  A frozen last layer has NO gradient (DINO
         cancel_gradients_last_layer: p.grad = None), so it is left out of the clip norm and skipped by AdamW."""
-        loss, grads, s_out, t_out, bsum = self.forward_backward(tiles_u8, teacher_temp)
+        loss, grads, s_out, t_out, bsum = self.forward_backward(tiles_u8, teacher_temp, drop)
         if not train_last_layer:
             grads["head.last_layer.weight_v"] = None
         gn = grad_norm(grads)
@@ -94,16 +96,16 @@ class SupervisedOracle:
         self.smoothing = smoothing
         self.opt = vo.AdamW(self.p, lr, wd)
 
-    def forward_backward(self, tiles_u8, target):
+    def forward_backward(self, tiles_u8, target, drop=None):
         x = vo.normalize_window(tiles_u8, (0, 0, self.img), dtype=self.dtype)
         sp = _leafify(self.p)
-        logits = vo.vit_logits(sp, x, self.arch)
+        logits = vo.vit_logits(sp, x, self.arch, drop=drop)
         loss = vo.softmax_lsce(logits, target, self.smoothing)
         loss.backward()
         return loss.detach(), {k: v.grad for k, v in sp.items()}, logits.detach()
 
-    def step(self, tiles_u8, target, lr=None):
-        loss, grads, logits = self.forward_backward(tiles_u8, target)
+    def step(self, tiles_u8, target, lr=None, drop=None):
+        loss, grads, logits = self.forward_backward(tiles_u8, target, drop)
         gn = grad_norm(grads)
         self.opt.step(grads, lr)
         return dict(loss=float(loss), grad_norm=gn, logits=logits)

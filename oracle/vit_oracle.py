@@ -152,13 +152,29 @@ def attention(x, p, pre, num_heads):
     return y @ p[pre + "proj.weight"].t() + p[pre + "proj.bias"]
 
 
-def block(x, p, i, num_heads):
-    """vit.pyc@L146-152 Block.forward (drop_path = Identity at rate 0)."""
+def drop_path_factors(depth: int, n_img: int, rate: float, gen: torch.Generator) -> torch.Tensor:
+    """Stochastic depth draws (timm DropPath behind --drop-path, vit.pyc@L66-74; train.py:283-288): block i drops a sample's
+    residual branch with probability rate * i / (depth - 1) (vit.pyc@L186 linspace rule) and scales the kept ones by
+    1 / keep.  Returns f32 [depth, 2, n_img]: the factor keep_mask / keep_prob per block, branch (attention, MLP), image."""
+    out = torch.ones(depth, 2, n_img)
+    for i in range(depth):
+        p_drop = rate * i / max(depth - 1, 1)
+        if p_drop > 0:
+            keep = 1.0 - p_drop
+            out[i] = (torch.rand(2, n_img, generator=gen) < keep).float() / keep
+    return out
+
+
+def block(x, p, i, num_heads, drop=None):
+    """vit.pyc@L146-152 Block.forward.  ``drop``: f32 [2, B] stochastic-depth factors of this block's two branches
+    (drop_path_factors), None = Identity (rate 0 / evaluation)."""
     b = f"blocks.{i}."
-    x = x + attention(layer_norm(x, p[b + "norm1.weight"], p[b + "norm1.bias"]), p, b + "attn.", num_heads)
+    a = attention(layer_norm(x, p[b + "norm1.weight"], p[b + "norm1.bias"]), p, b + "attn.", num_heads)
+    x = x + (a if drop is None else a * drop[0].to(a.dtype)[:, None, None])
     h = layer_norm(x, p[b + "norm2.weight"], p[b + "norm2.bias"])
     h = gelu(h @ p[b + "mlp.fc1.weight"].t() + p[b + "mlp.fc1.bias"])
-    return x + (h @ p[b + "mlp.fc2.weight"].t() + p[b + "mlp.fc2.bias"])
+    h = h @ p[b + "mlp.fc2.weight"].t() + p[b + "mlp.fc2.bias"]
+    return x + (h if drop is None else h * drop[1].to(h.dtype)[:, None, None])
 
 
 def prepare_tokens(x, p):
@@ -170,19 +186,20 @@ def prepare_tokens(x, p):
     return t + interpolate_pos_encoding(p["pos_embed"], t.shape[1] - 1, w, h)
 
 
-def vit_features(p, x, arch: str, return_tokens: bool = False):
-    """vit.pyc@L248-253 VisionTransformer.forward -> x[:, 0] after the final norm."""
+def vit_features(p, x, arch: str, return_tokens: bool = False, drop=None):
+    """vit.pyc@L248-253 VisionTransformer.forward -> x[:, 0] after the final norm.  ``drop``: [depth, 2, B] stochastic-depth
+    factors (training with --drop-path) or None."""
     a = ARCHS[arch]
     t = prepare_tokens(x, p)
     for i in range(a["depth"]):
-        t = block(t, p, i, a["num_heads"])
+        t = block(t, p, i, a["num_heads"], None if drop is None else drop[i])
     t = layer_norm(t, p["norm.weight"], p["norm.bias"])
     return t if return_tokens else t[:, 0]
 
 
-def vit_logits(p, x, arch: str):
+def vit_logits(p, x, arch: str, drop=None):
     """timm variant used at runtime (train.py:482-495): CLS -> head Linear."""
-    f = vit_features(p, x, arch)
+    f = vit_features(p, x, arch, drop=drop)
     return f @ p["head.weight"].t() + p["head.bias"]
 
 
@@ -273,15 +290,18 @@ def ema_update(teacher: Dict[str, torch.Tensor], student: Dict[str, torch.Tensor
 # --------------------------------------------------------------------------- #
 # multi-crop forward (row D1)
 # --------------------------------------------------------------------------- #
-def multicrop_forward(p, hp, crops: Sequence[torch.Tensor], arch: str):
+def multicrop_forward(p, hp, crops: Sequence[torch.Tensor], arch: str, drop=None):
     """Group consecutive crops of equal resolution, run the backbone once per
-    group on the concatenated batch, concat CLS features, head once."""
-    feats, i = [], 0
+    group on the concatenated batch, concat CLS features, head once.  ``drop``: [depth, 2, sum of crop batches]
+    stochastic-depth factors in crop order (every crop of every image is its own sample), or None."""
+    feats, i, img0 = [], 0, 0
     while i < len(crops):
         j = i
         while j < len(crops) and crops[j].shape[-1] == crops[i].shape[-1]:
             j += 1
-        feats.append(vit_features(p, torch.cat(list(crops[i:j])), arch))
+        x = torch.cat(list(crops[i:j]))
+        feats.append(vit_features(p, x, arch, drop=None if drop is None else drop[:, :, img0:img0 + x.shape[0]]))
+        img0 += x.shape[0]
         i = j
     return dino_head(hp, torch.cat(feats))
 

@@ -329,6 +329,59 @@ def test_create_model_seam(dev):
     with pytest.raises(KeyError):
         m.load_state_dict({"head.bias": sd["head.bias"]})
     with pytest.raises(ValueError, match="drop"):
-        models.create_model("vit_tiny", drop_path_rate=0.1, device=dev)
+        models.create_model("vit_tiny", drop_rate=0.1, device=dev)
+    md = models.create_model("vit_tiny", num_classes=2, img_size=64, batch=8, drop_path_rate=0.2, device=dev)
+    assert md.drop_path_rate == 0.2 and tuple(md.drop_path.sample().shape) == (12, 2, 8)
     with pytest.raises(ValueError, match="checkpoint_path"):
         models.create_model("vit_tiny", pretrained=True, device=dev)
+
+
+@gpu
+def test_drop_path_supervised_parity(dev):
+    """--drop-path (timm DropPath, vit.pyc@L66-74) on the unfused path (ViT-T: 128x128-tile GEMM epilogues + stand-alone
+    LayerNorm backward): engine and oracle apply the SAME per-image factors; logits, loss and gradients agree, and the factors
+    change the result (some branches dropped)."""
+    from gipvit.engine import SupervisedEngine
+    from oracle import step_oracle as so, vit_oracle as vo
+    orc = so.SupervisedOracle(arch="vit_tiny", img_size=64, num_classes=2, seed=0, lr=1e-3, wd=0.05)
+    eng = SupervisedEngine(arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.05, device=dev)
+    eng.load_state(orc.p)
+    tiles = vo.synth_tiles(8, 64, seed=1234)
+    tgt = torch.randint(0, 2, (8, 1), generator=torch.Generator().manual_seed(5))
+    drop = vo.drop_path_factors(12, 8, 0.5, torch.Generator().manual_seed(9))
+    assert float(drop.min()) == 0.0 and float(drop[0].min()) == 1.0           # block 0 never drops, deep blocks do
+    loss_0, _, _ = orc.forward_backward(tiles, tgt)
+    loss_r, grads_r, logits_r = orc.forward_backward(tiles, tgt, drop)
+    assert abs(float(loss_r) - float(loss_0)) > 1e-3
+    eng.set_drop_path(drop.to(dev))
+    eng.forward_backward(tiles.to(dev), tgt.to(dev))
+    torch.cuda.synchronize()
+    assert float((eng.logits.cpu() - logits_r).abs().max()) <= 2e-2 * max(float(logits_r.abs().max()), 1.0)
+    assert abs(float(eng.loss) - float(loss_r)) <= 1e-3
+    _check_grads(eng.grads(), grads_r)
+    eng.set_drop_path(None)                                                    # evaluation: back to the plain forward
+    eng.forward_backward(tiles.to(dev), tgt.to(dev))
+    assert abs(float(eng.loss) - float(loss_0)) <= 1e-3
+
+
+@gpu
+def test_drop_path_dino_parity(dev):
+    """--drop-path on the fused path (ViT-S: full-row Linear + LayerNorm kernels forward and backward, grouped weight
+    gradients) in the DINO step: student with per-crop-image factors, teacher without."""
+    from gipvit.engine import DinoEngine
+    from oracle import step_oracle as so, vit_oracle as vo
+    K, B = 2048, 2
+    orc = so.DinoOracle(arch="vit_small", img_size=224, out_dim=K, seed=0, lr=5e-4, wd=0.04)
+    eng = DinoEngine(arch="vit_small", img_size=224, out_dim=K, batch=B, lr=5e-4, weight_decay=0.04, device=dev)
+    eng.load_state(orc.p, orc.hp)
+    tiles = vo.synth_tiles(B, 256, seed=77)
+    drop = vo.drop_path_factors(12, 10 * B, 0.3, torch.Generator().manual_seed(4))
+    loss_0 = orc.forward_backward(tiles)[0]
+    loss_r, grads_r, s_out, t_out, bsum = orc.forward_backward(tiles, drop=drop)
+    assert abs(float(loss_r) - float(loss_0)) > 1e-4
+    eng.set_hyper(); eng.set_drop_path(drop.to(dev))
+    eng.forward_backward(tiles.to(dev))
+    torch.cuda.synchronize()
+    assert abs(float(eng.loss) - float(loss_r)) <= 2.5e-3, (float(eng.loss), float(loss_r))   # B = 2 (the B = 8 configs hold 1e-3)
+    assert float((eng.hb_s.logits.cpu() - s_out).abs().max()) <= 3e-2 * float(s_out.abs().max())
+    _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), f"{name} declared in gipvit.h but not exported"
     bound = set(_lib.ENTRY_POINTS) | set(_lib.PLAIN_SYMBOLS)
     assert declared == bound, (declared - bound, bound - declared)
-    assert _lib.lib.gv_version() == 4 and _lib.lib.gv_target() == b"gfx950"
+    assert _lib.lib.gv_version() == 5 and _lib.lib.gv_target() == b"gfx950"
 
 
 def test_struct_layout_matches_header():
@@ -252,13 +252,23 @@ def test_every_used_flag_is_read_by_the_driver():
         elif e["flags"][0] != "data":
             assert reads == 0, f"{e['flags']} is read by train.py but marked used=False"
     # values the build cannot honour are refused before any GPU work
-    for bad in (["--drop", "0.1"], ["--drop-path", "0.1"], ["--pretrained"], ["--clip-mode", "agc"], ["--in-chans", "1"],
+    for bad in (["--drop", "0.1"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "agc"], ["--in-chans", "1"],
                 ["--input-size", "3", "224", "200"], ["--dino", "--supervised"]):
         args, _ = train.parse_args(["--model", "vit_tiny"] + bad)
         with pytest.raises(SystemExit):
             train.check_supported(args, lambda m: None)
-    args, _ = train.parse_args(["--model", "vit_tiny", "--input-size", "3", "64", "64", "--amp", "--amp-dtype", "bfloat16"])
+    args, _ = train.parse_args(["--model", "vit_tiny", "--input-size", "3", "64", "64", "--amp", "--amp-dtype", "bfloat16", "--drop-path", "0.1"])
     assert train.check_supported(args, lambda m: None) == 64
+    # --drop-path draws (gipvit.droppath): block 0 never drops, factors are 0 or 1 / keep, expectation 1
+    import numpy as np
+    from gipvit.droppath import DropPathSampler
+    sp = DropPathSampler(12, 4000, 0.2, seed=3, device="cpu")
+    f = sp.sample_host()
+    assert f.shape == (12, 2, 4000) and float(f[0].min()) == 1.0 and set(np.unique(f[11]).tolist()) == {0.0, np.float32(1.0 / 0.8)}
+    assert abs(float(f[11].mean()) - 1.0) < 0.04
+    assert torch.equal(sp.sample().cpu(), sp.dev[sp.k].cpu())
+    with pytest.raises(ValueError):
+        DropPathSampler(12, 8, 1.0, 0, "cpu")
     ns = lambda **k: type("A", (), dict(warmup_teacher_temp=0.04, teacher_temp=0.07, **k))
     assert train.teacher_temp_at(ns(warmup_teacher_temp_epochs=0), 0) == 0.07          # no warm-up: the final temperature from step 0
     assert train.teacher_temp_at(ns(warmup_teacher_temp_epochs=3), 0) == 0.04 and abs(train.teacher_temp_at(ns(warmup_teacher_temp_epochs=3), 1) - 0.055) < 1e-12

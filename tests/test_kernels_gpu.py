@@ -618,3 +618,60 @@ def test_augment_blur_and_fill(dev):
     ref[1] = torch.tensor([0.25, -0.5, 1.5]).view(3, 1, 1)
     ref_p = ref.view(2, 3, 4, 16, 4, 16).permute(0, 2, 4, 1, 3, 5)                          # [img, prow, pcol, c, py, px]
     close(got, ref_p, 8e-3, 8e-3, "patchify fill")
+
+
+def test_stochastic_depth_row_scales(dev):
+    """gv_expand_rows, the RESID row factor of gv_linear, gv_linear_ln_fwd's row_scale and the gb_scale of both LayerNorm
+    backward forms."""
+    o, l = ops(), L()
+    g = torch.Generator().manual_seed(12)
+    # expand: two segments (3 images x 5 tokens, 2 images x 3 tokens), 4 branches
+    row_img = torch.tensor([0] * 5 + [1] * 5 + [2] * 5 + [3] * 3 + [4] * 3, dtype=torch.int32, device=dev)
+    per = torch.rand(4, 5, generator=g).to(dev)
+    rows = torch.empty(4, 21, device=dev)
+    o.expand_rows(per, row_img, rows, 4, 5, 21)
+    assert torch.equal(rows, per[:, row_img.long()])
+    # gv_linear RESID with a row factor (exact on integers; factors 0 / 2)
+    M, N, K = 300, 192, 128
+    A, B = ints((M, K), dev, seed=41), ints((N, K), dev, seed=42)
+    bias = (torch.arange(N, device=dev) % 3).float(); resid = torch.randint(-4, 5, (M, N), generator=g).float().to(dev)
+    rs = (torch.randint(0, 2, (M,), generator=g).float() * 2).to(dev)
+    C = torch.empty(M, N, device=dev)
+    o.linear(A, B, C, M, N, K, epilogue=l.EPI_BIAS | l.EPI_RESID, bias=bias, resid=resid, row_scale=rs)
+    assert torch.equal(C, (A.float() @ B.float().t() + bias) * rs[:, None] + resid)
+    # fused Linear + LayerNorm forward
+    M, K = 2000, 384
+    A, W = ints((M, K), dev, seed=43), ints((384, K), dev, seed=44)
+    resid = torch.randint(-4, 5, (M, 384), generator=g).float().to(dev)
+    rs = (torch.randint(0, 2, (M,), generator=g).float() * 2).to(dev)
+    out = torch.empty(M, 384, device=dev)
+    o.linear_ln_fwd(A, W, out, M, K, resid=resid, row_scale=rs)
+    assert torch.equal(out, (A.float() @ W.float().t()) * rs[:, None] + resid)
+    # LayerNorm backward: g unscaled, gb = bf16(g * s), third column sum over the scaled rows -- stand-alone and fused forms
+    rows_n, D = 1000, 384
+    x = torch.randn(rows_n, D, generator=g).to(dev); gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev); beta = torch.zeros(D, device=dev)
+    y, mean, rstd = o.layernorm_fwd(x, gamma, beta, rows_n, D)
+    dy = torch.randn(rows_n, D, generator=g).to(dev).to(bf16)
+    sc = (torch.randint(0, 2, (rows_n,), generator=g).float() * 1.25).to(dev)
+    outs = []
+    for s_ in (None, sc):
+        gbuf = torch.zeros(rows_n, D, device=dev); gb = torch.empty(rows_n, D, dtype=bf16, device=dev)
+        parts = torch.zeros(l.LN_PARTIAL_BLOCKS, 3, D, device=dev)
+        o.layernorm_bwd(dy, x, mean, rstd, gamma, gbuf, gb, parts, rows_n, D, g_init=True, gb_scale=s_)
+        d2 = torch.zeros(D, device=dev); o.ln_finalize(parts, l.LN_PARTIAL_BLOCKS, D, None, None, d2)
+        outs.append((gbuf, gb, d2))
+    (g0, gb0, s0), (g1, gb1, s1) = outs
+    assert torch.equal(g0, g1) and torch.equal(gb1.float(), (g0 * sc[:, None]).to(bf16).float())
+    close(s1, (g0 * sc[:, None]).sum(0), 1e-3, 1e-3, "scaled column sum")
+    Kd = 256
+    dY = ints((rows_n, Kd), dev, seed=45); Wb = ints((Kd, D), dev, seed=46)
+    outs = []
+    for s_ in (None, sc):
+        gbuf = torch.zeros(rows_n, D, device=dev); gb = torch.empty(rows_n, D, dtype=bf16, device=dev)
+        parts = torch.zeros(l.LN_PARTIAL_BLOCKS, 3, D, device=dev)
+        nb = o.linear_ln_bwd(dY, Wb, x, mean, rstd, gamma, gbuf, gb, parts, rows_n, Kd, g_init=True, gb_scale=s_)
+        d2 = torch.zeros(D, device=dev); o.ln_finalize(parts, nb, D, None, None, d2)
+        outs.append((gbuf, gb, d2))
+    (g0, gb0, s0), (g1, gb1, s1) = outs
+    assert torch.equal(g0, g1) and torch.equal(gb1.float(), (g0 * sc[:, None]).to(bf16).float())
+    close(s1, (g0 * sc[:, None]).sum(0), 1e-3, 1e-3, "scaled column sum (fused)")

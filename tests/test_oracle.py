@@ -323,3 +323,26 @@ def test_augment_oracle_geometry_and_host_sampler():
         if fill is not None:
             for i, d in enumerate(dicts):
                 assert fill[i, 7] == (1.0 if d["fill"] else 0.0) and (not d["fill"] or np.allclose(fill[i, :7], d["fill"]))
+
+
+def test_drop_path_oracle_matches_stochastic_depth_module():
+    """vo.block with explicit factors == x + DropPath(branch) written with torch modules semantics (timm drop_path: keep mask
+    / keep_prob per sample), and drop_path_factors follows the linspace rule (block 0 never drops; expectation 1)."""
+    from oracle import vit_oracle as vo
+    torch.manual_seed(0)
+    p = vo.init_vit("vit_tiny", 64, 0, seed=3)
+    x = torch.randn(5, 17, 192)
+    f = torch.tensor([[1.0, 0.0, 2.0, 0.0, 2.0], [0.0, 1.25, 1.25, 0.0, 1.25]])
+    y = vo.block(x, p, 4, 3, drop=f)
+    b = "blocks.4."
+    a = vo.attention(vo.layer_norm(x, p[b + "norm1.weight"], p[b + "norm1.bias"]), p, b + "attn.", 3)
+    x1 = x + a * f[0].view(5, 1, 1)
+    h = vo.gelu(vo.layer_norm(x1, p[b + "norm2.weight"], p[b + "norm2.bias"]) @ p[b + "mlp.fc1.weight"].t() + p[b + "mlp.fc1.bias"])
+    ref = x1 + (h @ p[b + "mlp.fc2.weight"].t() + p[b + "mlp.fc2.bias"]) * f[1].view(5, 1, 1)
+    assert torch.allclose(y, ref, atol=1e-6)
+    assert torch.equal(y[3], x[3])                                   # both branches dropped: the sample passes through
+    d = vo.drop_path_factors(12, 4000, 0.2, torch.Generator().manual_seed(1))
+    assert float(d[0].min()) == 1.0 and float(d[0].max()) == 1.0
+    keep_last = 1.0 - 0.2
+    assert set(torch.unique(d[11]).tolist()) == {0.0, 1.0 / keep_last}
+    assert abs(float(d[11].mean()) - 1.0) < 0.03 and abs(float((d[6] > 0).float().mean()) - (1 - 0.2 * 6 / 11)) < 0.03

@@ -147,3 +147,20 @@ def test_train_dino_checkpoint_and_resume(dev, tmp_path):
         assert _rel(r1["state_dict_ema"][k], te[k]) < 1e-5, k
         assert _rel(r1["state_dict"][k], sd[k]) < 2e-3, k
     assert _rel(r1["dino_center"], ck1["dino_center"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_train_dino_drop_path(dev, tmp_path):
+    """--drop-path through the driver (DINO's own default is 0.1): the student trains with per-crop stochastic depth, the run
+    is reproducible from its seed and differs from the run without it."""
+    sys.path.insert(0, ROOT)
+    import train
+    base = ["--dino", "--model", "vit_small", "--dataset", "synthetic", "-b", "2", "--out-dim", "1024", "--batches-per-epoch", "3", "--lr", "1e-4",
+            "--epochs", "1", "--log-interval", "1", "--output", str(tmp_path), "--seed", "7", "--no-validate"]
+    for name, extra in (("dp_a", ["--drop-path", "0.3"]), ("dp_b", ["--drop-path", "0.3"]), ("plain", [])):
+        assert train.main(base + ["--experiment", name] + extra) == 0
+    w = {n: torch.load(tmp_path / n / "last.pth.tar", weights_only=True)["state_dict"]["backbone.blocks.11.mlp.fc2.weight"] for n in ("dp_a", "dp_b", "plain")}
+    assert _rel(w["dp_a"], w["dp_b"]) < 1e-4                   # same seed, same draws (atomics: not bitwise)
+    assert _rel(w["dp_a"], w["plain"]) > 1e-4
+    rows = list(csv.DictReader(open(tmp_path / "dp_a" / "summary.csv")))
+    assert 5.0 < float(rows[0]["train_loss"]) < 8.0

@@ -112,9 +112,10 @@ def check_supported(args, log=_logger.warning):
     if args.drop:
         raise SystemExit(f"--drop {args.drop}: dropout is not built into the fused epilogues (reference train.py:283-284, vit.pyc@L98-104); "
                          "only the reference default 0.0 is supported")
-    if args.drop_path:
-        raise SystemExit(f"--drop-path {args.drop_path}: stochastic depth is not built (reference train.py:287-288, vit.pyc@L66-74); "
-                         "only the reference default (None / 0) is supported")
+    if args.drop_path is not None and not 0.0 <= args.drop_path < 1.0:
+        raise SystemExit(f"--drop-path {args.drop_path}: stochastic depth needs 0 <= rate < 1 (reference train.py:287-288, vit.pyc@L66-74)")
+    if args.drop_connect:
+        raise SystemExit("--drop-connect is the deprecated spelling of --drop-path (reference train.py:285-286): pass --drop-path")
     if args.pretrained and not args.initial_checkpoint:
         raise SystemExit("--pretrained downloads weights by URL (reference train.py:482-485): there is no network here -- "
                          "pass the file with --initial-checkpoint instead")
@@ -196,7 +197,7 @@ def main(argv=None):
             _logger.warning("--log-wandb: wandb unavailable (%s); metrics go to the log and summary.csv only", ex)
 
     from gipvit import models as M, sched as S, data as D, transformations as T
-    from gipvit.engine import DinoEngine, SupervisedEngine, FeatureExtractor, Weights
+    from gipvit.engine import ARCHS, DinoEngine, SupervisedEngine, FeatureExtractor, Weights
     from gipvit.checkpoint import CheckpointSaver, load_checkpoint_file
     from gipvit.validate import validate
     arch = M.resolve_arch(args.model)
@@ -342,6 +343,12 @@ def main(argv=None):
     torch.cuda.set_stream(torch.cuda.Stream(dev, priority=-1))
     # tiles reach HBM one batch ahead of the step: pinned staging + a copy stream (replaces pin_memory workers, train.py:732)
     loader = D.DevicePrefetcher(source, dev, (B, tile, tile, 3), augmenter)
+    # --drop-path (train.py:287-288): stochastic depth on the training passes (DINO: the student's; every crop of every tile is
+    # its own sample); validation runs on its own forward-only group and never sees it
+    drop_sampler = None
+    if args.drop_path:
+        from gipvit.droppath import DropPathSampler
+        drop_sampler = DropPathSampler(ARCHS[arch]["depth"], (eng.V * B) if args.dino else B, args.drop_path, args.seed + 17 * rank, dev)
     cur_lr = lr
     # ---- epoch loop (train.py:905-977) / step loop (988-1143)
     for epoch in range(start_epoch, args.epochs):
@@ -358,6 +365,8 @@ def main(argv=None):
                 data, fill = augmenter.run(data, mb["AugParams"]), mb["Fill"]
             data_time.update(time.time() - end)
             cur_lr = schedule.at(epoch, batch_idx)
+            if drop_sampler is not None:
+                eng.set_drop_path(drop_sampler.sample())
             if args.dino:
                 it = epoch * updates_per_epoch + batch_idx
                 sch = dict(lr=cur_lr, wd=S.cosine_between(args.weight_decay, args.weight_decay_end, it, total_updates),
