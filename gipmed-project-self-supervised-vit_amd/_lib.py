@@ -101,6 +101,10 @@ ENTRY_POINTS = {
     "gv_dino_loss": gv_dino_loss_args, "gv_center_update": gv_center_update_args, "gv_softmax_lsce": gv_softmax_lsce_args,
     "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_store_f32": gv_store_f32_args, "gv_sumsq": gv_sumsq_args,
     "gv_adamw_ema": gv_adamw_ema_args,
+    # fp32 operand mode: the same structs with every bf16 buffer read / written as f32
+    "gv_linear_f32": gv_linear_args, "gv_attention_fwd_f32": gv_attention_fwd_args, "gv_attention_bwd_f32": gv_attention_bwd_args,
+    "gv_layernorm_fwd_f32": gv_layernorm_fwd_args, "gv_layernorm_bwd_f32": gv_layernorm_bwd_args, "gv_patchify_f32": gv_patchify_args,
+    "gv_tokens_bwd_f32": gv_tokens_bwd_args,
 }
 PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read",
                  "gv_linear_ln_blocks")

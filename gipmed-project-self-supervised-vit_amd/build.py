@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libgipvit_hip.so")
-SOURCES = ["abi", "gemm", "panel", "layernorm", "rowops", "patch", "augment", "attention", "dino_loss", "optim"]
+SOURCES = ["abi", "gemm", "panel", "layernorm", "rowops", "patch", "augment", "attention", "f32path", "dino_loss", "optim"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 

@@ -1,0 +1,397 @@
+// fp32 operand mode of the encoder path (SURVEY 8d, fp32 column): the reference's default arithmetic is fp32
+// (train.py runs without --amp unless asked), so the parity gates that are stated at 1e-4 (logits, loss) and 1e-3
+// (gradient norm) can only be held by a path whose activations, GEMM operands and attention operands are f32.
+// This file is that path's own kernels -- the Linear (v_mfma_f32_16x16x4_f32, every epilogue of gv_linear with the
+// exact erf GELU) and the attention forward / backward; LayerNorm, patchify and the token scatter are f32-I/O
+// instantiations of the bf16 path's kernels (layernorm.hip, patch.hip, rowops.hip).
+//
+// It is a PARITY mode: correct by construction, full f32 everywhere, no split-K, no fused LayerNorm; its speed is
+// bounded by the f32 MFMA rate (1/16 of bf16) and nobody trains in it.  The training path stays bf16.
+#include "gv_common.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Linear: C[M,N] = op(A) op(B), 128x128 output tile per workgroup, 4 waves of 64x64 (4x4 MFMA 16x16x4 fragments),
+// k in steps of 16 through LDS images stored k-major ([k][row], row stride 144 floats: the 16 rows x 4 k of one
+// fragment read land in 64 different banks).  Operands may be row- or k-contiguous in memory; ragged edges are
+// zero-filled while staging, so any M, N, K is accepted.
+// ------------------------------------------------------------------------------------------------
+constexpr int LBM = 128, LBN = 128, LBK = 16, LLD = 144;
+
+struct LinP {
+    gv_linear_args a;
+    int vec_a, vec_b;     // 16-byte loads allowed (base and leading dimension aligned)
+};
+
+// one [128 rows x 16 k] operand tile: element (r, k) at X[r*ld + k] (kc) or X[k*ld + r] (!kc)
+__device__ __forceinline__ void tile_load(const float* __restrict__ X, long ld, bool kc, bool vec, int r0, int R, int k0, int K, f32x4 (&v)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        if (kc) {
+            const int r = r0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+            const float* p = X + (long)r * ld + k;
+            if (vec && r < R && k + 3 < K) v[j] = *(const f32x4*)p;
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[j][i] = (r < R && k + i < K) ? p[i] : 0.f;
+            }
+        } else {
+            const int k = k0 + (idx >> 5), r = r0 + (idx & 31) * 4;
+            const float* p = X + (long)k * ld + r;
+            if (vec && k < K && r + 3 < R) v[j] = *(const f32x4*)p;
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[j][i] = (k < K && r + i < R) ? p[i] : 0.f;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void tile_store(float* S, bool kc, const f32x4 (&v)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        if (kc) {
+            const int r = idx >> 2, k = (idx & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[(k + i) * LLD + r] = v[j][i];
+        } else {
+            *(f32x4*)(S + (idx >> 5) * LLD + (idx & 31) * 4) = v[j];
+        }
+    }
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_exact(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+}
+
+__global__ __launch_bounds__(256) void linear_f32_kernel(LinP p) {
+    const gv_linear_args& a = p.a;
+    __shared__ float As[LBK * LLD], Bs[LBK * LLD];
+    const float* A = (const float*)a.A;
+    const float* B = (const float*)a.B;
+    const int M = a.M, N = a.N, K = a.K;
+    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    const bool kcA = !a.trans_a, kcB = !a.trans_b;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wm = wave >> 1, wn = wave & 1, li = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = a.colsum_a != nullptr && blockIdx.x == 0;
+    float cs = 0.f;
+    f32x4 ra[2], rb[2];
+    tile_load(A, a.lda, kcA, p.vec_a, m0, M, 0, K, ra);
+    tile_load(B, a.ldb, kcB, p.vec_b, n0, N, 0, K, rb);
+    for (int k0 = 0; k0 < K; k0 += LBK) {
+        __syncthreads();                       // the previous step's fragment reads are done
+        tile_store(As, kcA, ra);
+        tile_store(Bs, kcB, rb);
+        __syncthreads();
+        if (k0 + LBK < K) {                    // next tile's loads fly under this tile's MFMAs
+            tile_load(A, a.lda, kcA, p.vec_a, m0, M, k0 + LBK, K, ra);
+            tile_load(B, a.ldb, kcB, p.vec_b, n0, N, k0 + LBK, K, rb);
+        }
+        if (do_cs && threadIdx.x < LBM) {
+#pragma unroll
+            for (int k = 0; k < LBK; ++k) cs += As[k * LLD + threadIdx.x];
+        }
+#pragma unroll
+        for (int kk = 0; kk < LBK / 4; ++kk) {
+            float af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = As[(kk * 4 + g) * LLD + wm * 64 + i * 16 + li];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = Bs[(kk * 4 + g) * LLD + wn * 64 + j * 16 + li];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (do_cs && threadIdx.x < LBM && m0 + (int)threadIdx.x < M) a.colsum_a[m0 + threadIdx.x] += cs;   // one workgroup per row block: no atomics
+
+    // epilogue, in gv_linear's documented order; accumulator fragment: row 4g + r, column li
+    const int e = a.epilogue;
+    const float alpha = a.alpha == 0.f ? 1.f : a.alpha;
+    float* C = (float*)a.C;
+    const float* aux_in = (const float*)a.aux_in;
+    float* aux_out = (float*)a.aux_out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + i * 16 + g * 4 + r;
+            if (m >= M) continue;
+            long orow = m;
+            int prow = 0;
+            if (e & GV_EPI_POS) { orow = m + m / a.P + 1; prow = (m % a.P) + 1; }
+            const float rs = ((e & GV_EPI_RESID) && a.row_scale) ? a.row_scale[m] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + li;
+                if (n >= N) continue;
+                float x = acc[i][j][r] * alpha;
+                if (e & GV_EPI_BIAS) x += a.bias[n];
+                if (e & GV_EPI_SAVE_PRE) aux_out[orow * a.ld_aux + n] = x;
+                if (e & GV_EPI_GELU) x = gelu_exact(x);
+                if (e & GV_EPI_DGELU) x *= dgelu_exact(aux_in[orow * a.ld_aux + n]);
+                if (e & GV_EPI_RESID) x = x * rs + a.resid[orow * a.ldr + n];
+                if (e & GV_EPI_POS) x += a.pos[(long)prow * N + n];
+                float* dst = C + orow * a.ldc + n;
+                if (e & GV_EPI_ACCUM) x += *dst;
+                *dst = x;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention, one (image, head) pair x 64 rows per workgroup.  The other side's rows sit in LDS as [N][65] f32
+// (lane = row reads are conflict-free across the odd stride, lane = column reads are unit-stride); every wave
+// takes one row at a time: lane j holds the score against row j (+64, +128 ...), a per-wave LDS strip hands the
+// 64-lane result back as a broadcast operand for the second product.  Softmax statistics are exact (expf, logf).
+// ------------------------------------------------------------------------------------------------
+constexpr int ALD = 65, AMAXC = 5, AMAXN = 260;
+
+__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, long ld, int N) {
+    for (int e = threadIdx.x; e < N * 16; e += 256) {
+        const int n = e >> 4, d = (e & 15) * 4;
+        const f32x4 v = *(const f32x4*)(src + (long)n * ld + d);
+        float* o = dst + n * ALD + d;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(gv_attention_fwd_args a) {
+    extern __shared__ float sm[];
+    const int N = a.N, H = a.H, img = blockIdx.x / H, h = blockIdx.x % H, D3 = 3 * H * 64;
+    const int NC = (N + 63) >> 6, NP = NC * 64;
+    float* Ks = sm;
+    float* Vs = Ks + N * ALD;
+    float* Pw = Vs + N * ALD;          // [4][NP]
+    float* Qw = Pw + 4 * NP;           // [4][64]
+    const float* base = (const float*)a.qkv + (long)img * N * D3 + h * 64;
+    stage_rows(Ks, base + H * 64, D3, N);
+    stage_rows(Vs, base + 2 * H * 64, D3, N);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int it = 0; it < 16; ++it) {
+        const int q = blockIdx.y * 64 + it * 4 + w;
+        const bool ok = q < N;
+        Qw[w * 64 + lane] = ok ? base[(long)q * D3 + lane] : 0.f;
+        __syncthreads();
+        float s[AMAXC];
+#pragma unroll
+        for (int c = 0; c < AMAXC; ++c) s[c] = 0.f;
+        for (int d = 0; d < 64; ++d) {
+            const float qd = Qw[w * 64 + d];
+#pragma unroll
+            for (int c = 0; c < AMAXC; ++c)
+                if (c < NC) s[c] = fmaf(qd, Ks[min(c * 64 + lane, N - 1) * ALD + d], s[c]);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < AMAXC; ++c)
+            if (c < NC) { s[c] = (c * 64 + lane < N) ? s[c] * a.scale : -INFINITY; mx = fmaxf(mx, s[c]); }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < AMAXC; ++c)
+            if (c < NC) { s[c] = expf(s[c] - mx); sum += s[c]; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int c = 0; c < AMAXC; ++c)
+            if (c < NC) Pw[w * NP + c * 64 + lane] = s[c] * inv;
+        __syncthreads();
+        float o = 0.f;
+        for (int j = 0; j < N; ++j) o = fmaf(Pw[w * NP + j], Vs[j * ALD + lane], o);
+        if (ok) {
+            ((float*)a.o)[((long)img * N + q) * (H * 64) + h * 64 + lane] = o;
+            if (lane == 0) a.lse[((long)img * H + h) * N + q] = mx + logf(sum);
+        }
+    }
+}
+
+// dQ: query rows against all keys.  P = exp(scale S - lse), dP = dO V^T, dS = P (dP - delta), dQ = scale dS K
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(gv_attention_bwd_args a) {
+    extern __shared__ float sm[];
+    const int N = a.N, H = a.H, img = blockIdx.x / H, h = blockIdx.x % H, D3 = 3 * H * 64, D = H * 64;
+    const int NC = (N + 63) >> 6, NP = NC * 64;
+    float* Ks = sm;
+    float* Vs = Ks + N * ALD;
+    float* Dw = Vs + N * ALD;          // [4][NP] dS strip
+    float* Qw = Dw + 4 * NP;           // [4][64]
+    float* Gw = Qw + 4 * 64;           // [4][64] dO row
+    const float* base = (const float*)a.qkv + (long)img * N * D3 + h * 64;
+    stage_rows(Ks, base + H * 64, D3, N);
+    stage_rows(Vs, base + 2 * H * 64, D3, N);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int it = 0; it < 16; ++it) {
+        const int q = blockIdx.y * 64 + it * 4 + w;
+        const bool ok = q < N;
+        const long orow = ((long)img * N + (ok ? q : 0)) * D + h * 64 + lane;
+        const float go = ok ? ((const float*)a.d_o)[orow] : 0.f;
+        const float oo = ok ? ((const float*)a.o)[orow] : 0.f;
+        Qw[w * 64 + lane] = ok ? base[(long)q * D3 + lane] : 0.f;
+        Gw[w * 64 + lane] = go;
+        const float delta = wave_sum(go * oo);
+        const float lse = ok ? a.lse[((long)img * H + h) * N + q] : 0.f;
+        __syncthreads();
+        float s[AMAXC], dp[AMAXC];
+#pragma unroll
+        for (int c = 0; c < AMAXC; ++c) s[c] = dp[c] = 0.f;
+        for (int d = 0; d < 64; ++d) {
+            const float qd = Qw[w * 64 + d], gd = Gw[w * 64 + d];
+#pragma unroll
+            for (int c = 0; c < AMAXC; ++c)
+                if (c < NC) {
+                    const int j = min(c * 64 + lane, N - 1);
+                    s[c] = fmaf(qd, Ks[j * ALD + d], s[c]);
+                    dp[c] = fmaf(gd, Vs[j * ALD + d], dp[c]);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < AMAXC; ++c)
+            if (c < NC) {
+                const float pj = (c * 64 + lane < N) ? expf(s[c] * a.scale - lse) : 0.f;
+                Dw[w * NP + c * 64 + lane] = pj * (dp[c] - delta);
+            }
+        __syncthreads();
+        float dq = 0.f;
+        for (int j = 0; j < N; ++j) dq = fmaf(Dw[w * NP + j], Ks[j * ALD + lane], dq);
+        if (ok) ((float*)a.dqkv)[((long)img * N + q) * D3 + h * 64 + lane] = dq * a.scale;
+    }
+}
+
+// dK, dV: key rows against all queries.  dV = P^T dO, dK = scale dS^T Q
+__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(gv_attention_bwd_args a) {
+    extern __shared__ float sm[];
+    const int N = a.N, H = a.H, img = blockIdx.x / H, h = blockIdx.x % H, D3 = 3 * H * 64, D = H * 64;
+    const int NC = (N + 63) >> 6, NP = NC * 64;
+    float* Qs = sm;
+    float* Gs = Qs + N * ALD;          // dO rows
+    float* Ls = Gs + N * ALD;          // [NP] lse
+    float* Dl = Ls + NP;               // [NP] delta
+    float* Pw = Dl + NP;               // [4][NP] P strip
+    float* Dw = Pw + 4 * NP;           // [4][NP] dS strip
+    float* Kw = Dw + 4 * NP;           // [4][64]
+    float* Vw = Kw + 4 * 64;           // [4][64]
+    const float* base = (const float*)a.qkv + (long)img * N * D3 + h * 64;
+    const float* dO = (const float*)a.d_o + (long)img * N * D + h * 64;
+    const float* O = (const float*)a.o + (long)img * N * D + h * 64;
+    stage_rows(Qs, base, D3, N);
+    stage_rows(Gs, dO, D, N);
+    for (int i = threadIdx.x; i < N; i += 256) Ls[i] = a.lse[((long)img * H + h) * N + i];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int i = w; i < N; i += 4) {
+        const float d = wave_sum(Gs[i * ALD + lane] * O[(long)i * D + lane]);
+        if (lane == 0) Dl[i] = d;
+    }
+    for (int it = 0; it < 16; ++it) {
+        const int j = blockIdx.y * 64 + it * 4 + w;
+        const bool ok = j < N;
+        Kw[w * 64 + lane] = ok ? base[(long)j * D3 + H * 64 + lane] : 0.f;
+        Vw[w * 64 + lane] = ok ? base[(long)j * D3 + 2 * H * 64 + lane] : 0.f;
+        __syncthreads();               // (first pass: also publishes Dl)
+        float s[AMAXC], dp[AMAXC];
+#pragma unroll
+        for (int c = 0; c < AMAXC; ++c) s[c] = dp[c] = 0.f;
+        for (int d = 0; d < 64; ++d) {
+            const float kd = Kw[w * 64 + d], vd = Vw[w * 64 + d];
+#pragma unroll
+            for (int c = 0; c < AMAXC; ++c)
+                if (c < NC) {
+                    const int i = min(c * 64 + lane, N - 1);
+                    s[c] = fmaf(kd, Qs[i * ALD + d], s[c]);
+                    dp[c] = fmaf(vd, Gs[i * ALD + d], dp[c]);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < AMAXC; ++c)
+            if (c < NC) {
+                const int i = c * 64 + lane;
+                const float pi = i < N ? expf(s[c] * a.scale - Ls[i]) : 0.f;
+                Pw[w * NP + i] = pi;
+                Dw[w * NP + i] = i < N ? pi * (dp[c] - Dl[i]) : 0.f;
+            }
+        __syncthreads();
+        float dv = 0.f, dk = 0.f;
+        for (int i = 0; i < N; ++i) {
+            dv = fmaf(Pw[w * NP + i], Gs[i * ALD + lane], dv);
+            dk = fmaf(Dw[w * NP + i], Qs[i * ALD + lane], dk);
+        }
+        if (ok) {
+            float* dst = (float*)a.dqkv + ((long)img * N + j) * D3 + h * 64 + lane;
+            dst[H * 64] = dk * a.scale;
+            dst[2 * H * 64] = dv;
+        }
+    }
+}
+
+template <typename Kern> int set_lds(Kern kern, int bytes, const char* name) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { gv_set_error("%s: hipFuncSetAttribute(%d): %s", name, bytes, hipGetErrorString(e)); return (int)e; }
+    return GV_OK;
+}
+
+}  // namespace
+
+extern "C" int gv_linear_f32(const gv_linear_args* a, void* stream) {
+    GV_REQUIRE(a && a->A && a->B && a->C, GV_E_NULL, "gv_linear_f32: null operand");
+    GV_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, GV_E_SHAPE, "gv_linear_f32: M,N,K must be > 0 (got %d,%d,%d)", a->M, a->N, a->K);
+    GV_REQUIRE(a->c_is_f32, GV_E_UNSUPPORTED, "gv_linear_f32: every operand is f32, c_is_f32 must be set");
+    const int e = a->epilogue;
+    GV_REQUIRE((e & ~GV_EPI_ALL) == 0, GV_E_UNSUPPORTED, "gv_linear_f32: epilogue 0x%x has bits outside the GV_EPI_* mask 0x%x", e, GV_EPI_ALL);
+    if (e & GV_EPI_BIAS) GV_REQUIRE(a->bias, GV_E_NULL, "gv_linear_f32: BIAS needs bias");
+    if (e & GV_EPI_RESID) GV_REQUIRE(a->resid, GV_E_NULL, "gv_linear_f32: RESID needs resid");
+    if (e & GV_EPI_DGELU) GV_REQUIRE(a->aux_in, GV_E_NULL, "gv_linear_f32: DGELU needs aux_in");
+    if (e & GV_EPI_SAVE_PRE) GV_REQUIRE(a->aux_out, GV_E_NULL, "gv_linear_f32: SAVE_PRE needs aux_out");
+    if (e & GV_EPI_POS) GV_REQUIRE(a->pos && a->P > 0, GV_E_NULL, "gv_linear_f32: POS needs pos and P");
+    if (a->colsum_a) GV_REQUIRE(a->trans_a, GV_E_UNSUPPORTED, "gv_linear_f32: colsum_a needs trans_a (it sums the dW product's A operand)");
+    GV_REQUIRE(gv_aligned(a->A, 4) && gv_aligned(a->B, 4) && gv_aligned(a->C, 4), GV_E_ALIGN, "gv_linear_f32: operands must be 4-byte aligned");
+    LinP p;
+    p.a = *a;
+    p.vec_a = gv_aligned(a->A, 16) && a->lda % 4 == 0;
+    p.vec_b = gv_aligned(a->B, 16) && a->ldb % 4 == 0;
+    const long tm = (a->M + LBM - 1) / LBM, tn = (a->N + LBN - 1) / LBN;
+    GV_REQUIRE(tm < 65536, GV_E_SHAPE, "gv_linear_f32: M=%d too large", a->M);
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)tn, (unsigned)tm), dim3(256), 0, (hipStream_t)stream, p);
+    GV_LAUNCH_CHECK("gv_linear_f32");
+    return GV_OK;
+}
+
+extern "C" int gv_attention_fwd_f32(const gv_attention_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->qkv && a->o && a->lse, GV_E_NULL, "gv_attention_fwd_f32: null pointer");
+    GV_REQUIRE(a->n_img > 0 && a->H > 0 && a->N > 0 && a->N <= AMAXN, GV_E_SHAPE, "gv_attention_fwd_f32: need 0 < N <= %d (got %d)", AMAXN, a->N);
+    GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16), GV_E_ALIGN, "gv_attention_fwd_f32: qkv/o must be 16-byte aligned");
+    const int NP = ((a->N + 63) / 64) * 64, lds = (2 * a->N * ALD + 4 * NP + 4 * 64) * 4;
+    int rc = set_lds(attn_fwd_f32_kernel, lds, "gv_attention_fwd_f32");
+    if (rc != GV_OK) return rc;
+    hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(a->n_img * a->H, (a->N + 63) / 64), dim3(256), lds, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_attention_fwd_f32");
+    return GV_OK;
+}
+
+extern "C" int gv_attention_bwd_f32(const gv_attention_bwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->qkv && a->o && a->d_o && a->lse && a->dqkv, GV_E_NULL, "gv_attention_bwd_f32: null pointer");
+    GV_REQUIRE(a->n_img > 0 && a->H > 0 && a->N > 0 && a->N <= AMAXN, GV_E_SHAPE, "gv_attention_bwd_f32: need 0 < N <= %d (got %d)", AMAXN, a->N);
+    GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16) && gv_aligned(a->d_o, 16) && gv_aligned(a->dqkv, 16), GV_E_ALIGN,
+               "gv_attention_bwd_f32: buffers must be 16-byte aligned");
+    const int NP = ((a->N + 63) / 64) * 64;
+    const int lds_q = (2 * a->N * ALD + 4 * NP + 8 * 64) * 4, lds_kv = (2 * a->N * ALD + 2 * NP + 8 * NP + 8 * 64) * 4;
+    int rc = set_lds(attn_bwd_dq_f32_kernel, lds_q, "gv_attention_bwd_f32");
+    if (rc != GV_OK) return rc;
+    rc = set_lds(attn_bwd_dkv_f32_kernel, lds_kv, "gv_attention_bwd_f32");
+    if (rc != GV_OK) return rc;
+    const dim3 grid(a->n_img * a->H, (a->N + 63) / 64);
+    hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, grid, dim3(256), lds_q, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, grid, dim3(256), lds_kv, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_attention_bwd_f32");
+    return GV_OK;
+}

@@ -38,7 +38,8 @@ template <int VEC> __device__ __forceinline__ void stb(bf16* p, const float* o) 
 
 // grid-stride over rows, one wave per row; the next row's loads are issued before the current
 // row's reductions so every wave keeps two rows of HBM traffic in flight
-template <int VEC>
+// F32IO: the fp32 parity mode (f32path.hip) keeps activations in f32 -- y / dy / gb are f32 rows instead of bf16
+template <int VEC, bool F32IO = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(gv_layernorm_fwd_args a) {
     constexpr int D = 192 * VEC;
     const int lane = threadIdx.x & 63;
@@ -72,13 +73,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(gv_layernorm_fwd_args a) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { const float d = v[i][j] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + a.eps);
-        bf16* y = (bf16*)a.y + (long)row * D;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             float o[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j];
-            stb<VEC>(y + (i * 64 + lane) * VEC, o);
+            if constexpr (F32IO) stf<VEC>((float*)a.y + (long)row * D + (i * 64 + lane) * VEC, o);
+            else stb<VEC>((bf16*)a.y + (long)row * D + (i * 64 + lane) * VEC, o);
         }
         if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
         if (!more) break;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(gv_layernorm_fwd_args a) {
     }
 }
 
-template <int VEC>
+template <int VEC, bool F32IO = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(gv_layernorm_bwd_args a) {
     constexpr int D = 192 * VEC;
     __shared__ float red[4][3][D];
@@ -104,7 +105,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(gv_layernorm_bwd_args a) {
     }
     for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
         const float* x = a.x + (long)row * a.x_stride;
-        const bf16* dy = (const bf16*)a.dy + (long)row * D;
         float* g = a.g + (long)row * a.g_stride;
         const float mean = a.mean[row], rstd = a.rstd[row];
         float xh[3][VEC], wdy[3][VEC], gv[3][VEC];
@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(gv_layernorm_bwd_args a) {
             const int c = (i * 64 + lane) * VEC;
             float xv[VEC], dv[VEC];
             ldf<VEC>(x + c, xv);
-            ldb<VEC>(dy + c, dv);
+            if constexpr (F32IO) ldf<VEC>((const float*)a.dy + (long)row * D + c, dv);
+            else ldb<VEC>((const bf16*)a.dy + (long)row * D + c, dv);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 xh[i][j] = (xv[j] - mean) * rstd;
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(gv_layernorm_bwd_args a) {
                 s_g[i][j] += gbv[j];
             }
             stf<VEC>(g + c, gv[i]);
-            if (a.gb) stb<VEC>((bf16*)a.gb + (long)row * a.gb_stride + c, gbv);
+            if (a.gb) {
+                if constexpr (F32IO) stf<VEC>((float*)a.gb + (long)row * a.gb_stride + c, gbv);
+                else stb<VEC>((bf16*)a.gb + (long)row * a.gb_stride + c, gbv);
+            }
         }
     }
     // block reduce of the three column sums -> partials[block][3][D]
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(gv_colsum_args a) {
 
 }  // namespace
 
-extern "C" int gv_layernorm_fwd(const gv_layernorm_fwd_args* a, void* stream) {
+template <bool F32IO> static int ln_fwd_launch(const gv_layernorm_fwd_args* a, void* stream) {
     GV_REQUIRE(a && a->x && a->gamma && a->beta && a->y && a->mean && a->rstd, GV_E_NULL, "gv_layernorm_fwd: null pointer");
     GV_REQUIRE(a->D == 192 || a->D == 384 || a->D == 768, GV_E_SHAPE, "gv_layernorm_fwd: D=%d not in {192,384,768}", a->D);
     GV_REQUIRE(a->rows > 0, GV_E_SHAPE, "gv_layernorm_fwd: rows must be > 0");
@@ -252,26 +256,30 @@ extern "C" int gv_layernorm_fwd(const gv_layernorm_fwd_args* a, void* stream) {
     const int blocks = (a->rows + 3) / 4;
     dim3 grid(blocks < 2048 ? blocks : 2048), block(256);     // 8 workgroups (32 waves) per CU, grid-stride over rows
     hipStream_t s = (hipStream_t)stream;
-    if (a->D == 192) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, *a);
-    else if (a->D == 384) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, *a);
-    else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, *a);
+    if (a->D == 192) hipLaunchKernelGGL((ln_fwd_kernel<1, F32IO>), grid, block, 0, s, *a);
+    else if (a->D == 384) hipLaunchKernelGGL((ln_fwd_kernel<2, F32IO>), grid, block, 0, s, *a);
+    else hipLaunchKernelGGL((ln_fwd_kernel<4, F32IO>), grid, block, 0, s, *a);
     GV_LAUNCH_CHECK("gv_layernorm_fwd");
     return GV_OK;
 }
+extern "C" int gv_layernorm_fwd(const gv_layernorm_fwd_args* a, void* stream) { return ln_fwd_launch<false>(a, stream); }
+extern "C" int gv_layernorm_fwd_f32(const gv_layernorm_fwd_args* a, void* stream) { return ln_fwd_launch<true>(a, stream); }
 
-extern "C" int gv_layernorm_bwd(const gv_layernorm_bwd_args* a, void* stream) {
+template <bool F32IO> static int ln_bwd_launch(const gv_layernorm_bwd_args* a, void* stream) {
     GV_REQUIRE(a && a->dy && a->x && a->mean && a->rstd && a->gamma && a->g && a->partials, GV_E_NULL, "gv_layernorm_bwd: null pointer");
     GV_REQUIRE(a->D == 192 || a->D == 384 || a->D == 768, GV_E_SHAPE, "gv_layernorm_bwd: D=%d not in {192,384,768}", a->D);
     GV_REQUIRE(a->rows > 0, GV_E_SHAPE, "gv_layernorm_bwd: rows must be > 0");
     GV_REQUIRE(a->x_stride % 4 == 0 && a->g_stride % 4 == 0 && a->gb_stride % 4 == 0, GV_E_ALIGN, "gv_layernorm_bwd: strides must be multiples of 4");
     dim3 grid(GV_LN_PARTIAL_BLOCKS), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (a->D == 192) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, *a);
-    else if (a->D == 384) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, *a);
-    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, *a);
+    if (a->D == 192) hipLaunchKernelGGL((ln_bwd_kernel<1, F32IO>), grid, block, 0, s, *a);
+    else if (a->D == 384) hipLaunchKernelGGL((ln_bwd_kernel<2, F32IO>), grid, block, 0, s, *a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<4, F32IO>), grid, block, 0, s, *a);
     GV_LAUNCH_CHECK("gv_layernorm_bwd");
     return GV_OK;
 }
+extern "C" int gv_layernorm_bwd(const gv_layernorm_bwd_args* a, void* stream) { return ln_bwd_launch<false>(a, stream); }
+extern "C" int gv_layernorm_bwd_f32(const gv_layernorm_bwd_args* a, void* stream) { return ln_bwd_launch<true>(a, stream); }
 
 extern "C" int gv_colsum_finalize(const gv_colsum_finalize_args* a, void* stream) {
     GV_REQUIRE(a && a->partials && a->out, GV_E_NULL, "gv_colsum_finalize: null pointer");

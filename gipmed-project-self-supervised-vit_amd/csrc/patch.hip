@@ -13,6 +13,7 @@
 
 namespace {
 
+template <bool F32OUT>      // fp32 parity mode: f32 patch rows (f32path.hip)
 __global__ __launch_bounds__(256) void patchify_kernel(gv_patchify_args a, int P, int side, float s0, float s1, float s2,
                                                        float o0, float o1, float o2) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -64,6 +65,13 @@ __global__ __launch_bounds__(256) void patchify_kernel(gv_patchify_args a, int P
                 if ((float)(x + i) >= f[2] && (float)(x + i) < f[3]) { px[0][i] = f[4]; px[1][i] = f[5]; px[2][i] = f[6]; }
         }
     }
+    if constexpr (F32OUT) {
+        float* out = (float*)a.patches + ip * 768 + py * 16;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) *(f32x4*)(out + c * 256 + i) = f32x4{px[c][i], px[c][i + 1], px[c][i + 2], px[c][i + 3]};
+    } else {
     bf16* out = (bf16*)a.patches + ip * 768 + py * 16;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -72,6 +80,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(gv_patchify_args a, int P
         for (int i = 0; i < 8; ++i) { lo[i] = (bf16)px[c][i]; hi[i] = (bf16)px[c][8 + i]; }
         *(bf16x8*)(out + c * 256) = lo;
         *(bf16x8*)(out + c * 256 + 8) = hi;
+    }
     }
 }
 
@@ -137,7 +146,7 @@ extern "C" int gv_crop_resize(const gv_crop_resize_args* a, void* stream) {
     return GV_OK;
 }
 
-extern "C" int gv_patchify(const gv_patchify_args* a, void* stream) {
+template <bool F32OUT> static int patchify_launch(const gv_patchify_args* a, void* stream) {
     GV_REQUIRE(a && a->tiles && a->patches, GV_E_NULL, "gv_patchify: null pointer");
     GV_REQUIRE(a->crop > 0 && a->crop % 16 == 0, GV_E_SHAPE, "gv_patchify: crop=%d must be a positive multiple of 16", a->crop);
     GV_REQUIRE(a->n_win >= 1 && a->n_win <= 16 && a->n_tiles >= 1 && a->n_img == a->n_win * a->n_tiles, GV_E_SHAPE,
@@ -151,8 +160,10 @@ extern "C" int gv_patchify(const gv_patchify_args* a, void* stream) {
     const long total = (long)a->n_img * P * 16;
     const float s0 = 1.0f / (255.0f * a->std[0]), s1 = 1.0f / (255.0f * a->std[1]), s2 = 1.0f / (255.0f * a->std[2]);
     const float o0 = -a->mean[0] / a->std[0], o1 = -a->mean[1] / a->std[1], o2 = -a->mean[2] / a->std[2];
-    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a, P, side,
+    hipLaunchKernelGGL(patchify_kernel<F32OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a, P, side,
                        s0, s1, s2, o0, o1, o2);
     GV_LAUNCH_CHECK("gv_patchify");
     return GV_OK;
 }
+extern "C" int gv_patchify(const gv_patchify_args* a, void* stream) { return patchify_launch<false>(a, stream); }
+extern "C" int gv_patchify_f32(const gv_patchify_args* a, void* stream) { return patchify_launch<true>(a, stream); }

@@ -16,6 +16,7 @@ __global__ void cls_rows_kernel(gv_cls_rows_args a) {
 // images and adds the partial into dpos with one f32 atomic (dpos is zeroed by the entry point
 // unless it accumulates); patch rows are also re-emitted compact in bf16.
 constexpr int TOK_IMG_PER_CHUNK = 8;
+template <typename PT>      // PT: element type of the compact patch rows (bf16; float in the fp32 parity mode)
 __global__ void tokens_bwd_kernel(gv_tokens_bwd_args a) {
     const int t = blockIdx.x;
     const int d = blockIdx.y * blockDim.x + threadIdx.x;
@@ -27,7 +28,7 @@ __global__ void tokens_bwd_kernel(gv_tokens_bwd_args a) {
     for (int i = i0; i < i1; ++i) {
         const float v = a.g[((long)i * a.N + t) * a.D + d];
         s += v;
-        if (t > 0) ((bf16*)a.gpatch)[((long)i * P + (t - 1)) * a.D + d] = (bf16)v;
+        if (t > 0) ((PT*)a.gpatch)[((long)i * P + (t - 1)) * a.D + d] = (PT)v;
     }
     atomicAdd(a.dpos + (long)t * a.D + d, s);
     if (t == 0 && a.dcls) atomicAdd(a.dcls + d, s);
@@ -232,7 +233,7 @@ extern "C" int gv_cls_rows(const gv_cls_rows_args* a, void* stream) {
     return GV_OK;
 }
 
-extern "C" int gv_tokens_bwd(const gv_tokens_bwd_args* a, void* stream) {
+template <typename PT> static int tokens_bwd_launch(const gv_tokens_bwd_args* a, void* stream) {
     GV_REQUIRE(a && a->g && a->gpatch && a->dpos, GV_E_NULL, "gv_tokens_bwd: null pointer");
     GV_REQUIRE(a->n_img > 0 && a->N > 1 && a->D > 0, GV_E_SHAPE, "gv_tokens_bwd: bad shape");
     if (!a->accumulate) {
@@ -240,11 +241,13 @@ extern "C" int gv_tokens_bwd(const gv_tokens_bwd_args* a, void* stream) {
         if (e == hipSuccess && a->dcls) e = hipMemsetAsync(a->dcls, 0, (size_t)a->D * sizeof(float), (hipStream_t)stream);
         if (e != hipSuccess) { gv_set_error("gv_tokens_bwd: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(tokens_bwd_kernel, dim3(a->N, (a->D + 255) / 256, (a->n_img + TOK_IMG_PER_CHUNK - 1) / TOK_IMG_PER_CHUNK), dim3(256), 0,
+    hipLaunchKernelGGL(tokens_bwd_kernel<PT>, dim3(a->N, (a->D + 255) / 256, (a->n_img + TOK_IMG_PER_CHUNK - 1) / TOK_IMG_PER_CHUNK), dim3(256), 0,
                        (hipStream_t)stream, *a);
     GV_LAUNCH_CHECK("gv_tokens_bwd");
     return GV_OK;
 }
+extern "C" int gv_tokens_bwd(const gv_tokens_bwd_args* a, void* stream) { return tokens_bwd_launch<bf16>(a, stream); }
+extern "C" int gv_tokens_bwd_f32(const gv_tokens_bwd_args* a, void* stream) { return tokens_bwd_launch<float>(a, stream); }
 
 extern "C" int gv_small_matmul(const gv_small_matmul_args* a, void* stream) {
     GV_REQUIRE(a && a->A && a->B && a->C, GV_E_NULL, "gv_small_matmul: null pointer");

@@ -146,10 +146,12 @@ class Arena:
 class Weights:
     """Accessor over one weight set of an arena (student or teacher) with a name prefix."""
 
-    def __init__(self, arena: Arena, prefix: str, teacher: bool = False):
-        self.a, self.prefix, self.teacher = arena, prefix, teacher
+    def __init__(self, arena: Arena, prefix: str, teacher: bool = False, fp32: bool = False):
+        self.a, self.prefix, self.teacher, self.fp32 = arena, prefix, teacher, fp32
 
-    def w(self, name):      # bf16 matrix used as a GEMM operand
+    def w(self, name):      # matrix used as a GEMM operand: the bf16 copy (the f32 master itself in the fp32 operand mode)
+        if self.fp32:
+            return self.f(name)
         return self.a.view(self.a.tb if self.teacher else self.a.pb, self.prefix + name)
 
     def f(self, name):      # f32 parameter (bias, LN, pos, cls)
@@ -181,7 +183,7 @@ def pos_interp_matrix(n_src_side: int, crop: int) -> torch.Tensor:
 # only attention, patch embedding and the CLS handling run per segment (multi-crop wrapper, row D1)
 # --------------------------------------------------------------------------- #
 class Segment:
-    def __init__(self, arch, n_img, crop, img_size, row0, img0, device, save, depth, H):
+    def __init__(self, arch, n_img, crop, img_size, row0, img0, device, save, depth, H, act=bf16):
         D = ARCHS[arch]["embed_dim"]
         self.n_img, self.crop, self.row0, self.img0 = n_img, crop, row0, img0
         self.P = (crop // 16) ** 2
@@ -189,13 +191,13 @@ class Segment:
         self.T = n_img * self.N
         e = lambda shape, dt: _empty(shape, dt, device)
         nb = depth if save else 1
-        self.patches = e((n_img * self.P, 768), bf16)
+        self.patches = e((n_img * self.P, 768), act)
         self.lse = [e((n_img, H, self.N), f32) for _ in range(nb)]
         self.fstats = [e((n_img,), f32) for _ in range(2)]
         self.pos = None if crop == img_size else e((self.N, D), f32)
         self.interp = None if crop == img_size else pos_interp_matrix(img_size // 16, crop).to(device)
         if save:
-            self.gpatch = e((n_img * self.P, D), bf16)
+            self.gpatch = e((n_img * self.P, D), act)
             self.dpos = e((self.N, D), f32)
 
     def rows(self, t: torch.Tensor) -> torch.Tensor:
@@ -203,15 +205,18 @@ class Segment:
 
 
 class VitGroup:
-    def __init__(self, arch: str, segments, img_size: int, device, save: bool):
-        """segments: [(n_img, crop), ...] in feature-row order."""
+    def __init__(self, arch: str, segments, img_size: int, device, save: bool, act=bf16):
+        """segments: [(n_img, crop), ...] in feature-row order.  ``act``: element type of the activation / gradient buffers
+        that feed GEMMs and attention -- bf16 on the training path, f32 in the fp32 operand mode (csrc/f32path.hip)."""
+        assert act in (bf16, f32)
+        self.act = act
         a = ARCHS[arch]
         D, depth, H = a["embed_dim"], a["depth"], a["num_heads"]
         self.save = save
         self.segs: List[Segment] = []
         row0 = img0 = 0
         for n_img, crop in segments:
-            sg = Segment(arch, n_img, crop, img_size, row0, img0, device, save, depth, H)
+            sg = Segment(arch, n_img, crop, img_size, row0, img0, device, save, depth, H, act)
             self.segs.append(sg)
             row0 += sg.T
             img0 += n_img
@@ -219,23 +224,23 @@ class VitGroup:
         T, nb = self.T, (depth if save else 1)
         e = lambda shape, dt: _empty(shape, dt, device)
         self.x = [e((T, D), f32) for _ in range(2 * depth + 1 if save else 3)]
-        self.xn1 = [e((T, D), bf16) for _ in range(nb)]
-        self.xn2 = [e((T, D), bf16) for _ in range(nb)]
-        self.qkv = [e((T, 3 * D), bf16) for _ in range(nb)]
-        self.o = [e((T, D), bf16) for _ in range(nb)]
-        self.hp = [e((T, 4 * D), bf16) for _ in range(nb)]
-        self.h = [e((T, 4 * D), bf16) for _ in range(nb)]
+        self.xn1 = [e((T, D), act) for _ in range(nb)]
+        self.xn2 = [e((T, D), act) for _ in range(nb)]
+        self.qkv = [e((T, 3 * D), act) for _ in range(nb)]
+        self.o = [e((T, D), act) for _ in range(nb)]
+        self.hp = [e((T, 4 * D), act) for _ in range(nb)]
+        self.h = [e((T, 4 * D), act) for _ in range(nb)]
         self.stats = [[e((T,), f32) for _ in range(4)] for _ in range(nb)]   # mean1, rstd1, mean2, rstd2
         if save:   # backward scratch
-            self.g, self.gb, self.gb2 = e((T, D), f32), e((T, D), bf16), e((T, D), bf16)
-            self.dh = e((T, 4 * D), bf16)
-            self.dxn = e((T, D), bf16)
-            self.dqkv = e((T, 3 * D), bf16)
-            self.do = e((T, D), bf16)
+            self.g, self.gb, self.gb2 = e((T, D), f32), e((T, D), act), e((T, D), act)
+            self.dh = e((T, 4 * D), act)
+            self.dxn = e((T, D), act)
+            self.dqkv = e((T, 3 * D), act)
+            self.do = e((T, D), act)
             # grouped weight gradients (one launch per block, queued on the side stream while the NEXT block runs): the dY
             # buffers alternate between two sets by block parity, so a block's set stays untouched until its group has run
-            self.gb3, self.gb4 = e((T, D), bf16), e((T, D), bf16)
-            self.dh_b, self.dqkv_b = e((T, 4 * D), bf16), e((T, 3 * D), bf16)
+            self.gb3, self.gb4 = e((T, D), act), e((T, D), act)
+            self.dh_b, self.dqkv_b = e((T, 4 * D), act), e((T, 3 * D), act)
 
         self.depth, self.device = depth, device
         self.rs = None            # stochastic depth: f32 [depth, 2, T] row factors of the attention / MLP branch (set_drop)
@@ -266,17 +271,18 @@ class VitGroup:
 
 
 class VitRunner:
-    def __init__(self, arch: str, img_size: int, device):
+    def __init__(self, arch: str, img_size: int, device, fp32: bool = False):
         a = ARCHS[arch]
         self.arch, self.D, self.depth, self.H, self.img_size = arch, a["embed_dim"], a["depth"], a["num_heads"], img_size
+        self.fp32 = fp32    # fp32 operand mode: one f32 kernel per op (no fused Linear + LayerNorm, no grouped dW)
         self.scale = 64 ** -0.5
         # full-row Linear + LayerNorm kernels (csrc/panel.hip) exist for the ViT-S width; GIPVIT_FUSED_LN=0 keeps the
         # round-1 pair (128x128-tile GEMM + stand-alone LayerNorm pass) for A/B runs
-        self.fused = self.D == 384 and os.environ.get("GIPVIT_FUSED_LN", "1") != "0"
+        self.fused = self.D == 384 and not fp32 and os.environ.get("GIPVIT_FUSED_LN", "1") != "0"
         # the four weight-gradient products of a block as ONE split-K launch (gv_linear_dw_group): a quarter of the slab
         # traffic and four times longer k-loops than four launches (ViT-S: 165 us per block at 950 TFLOP/s against
         # 4 x (51 + 7) us).  GIPVIT_GROUP_DW=0 keeps one launch per product for A/B runs.
-        self.group_dw = os.environ.get("GIPVIT_GROUP_DW", "1") != "0"
+        self.group_dw = not fp32 and os.environ.get("GIPVIT_GROUP_DW", "1") != "0"
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
         self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
@@ -873,7 +879,16 @@ class SupervisedEngine:
 
     def __init__(self, arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999),
                  eps=1e-8, smoothing=0.1, clip_grad: float = 0.0, mean=MEAN_RON, std=STD_RON, device="cuda:0", reducer=None,
-                 opt: str = "adamw", momentum: float = 0.9, train_backbone: bool = True, model_ema_decay: Optional[float] = None):
+                 opt: str = "adamw", momentum: float = 0.9, train_backbone: bool = True, model_ema_decay: Optional[float] = None,
+                 precision: str = "bf16"):
+        """``precision``: "bf16" (the training path: bf16 GEMM / attention operands, f32 accumulation and residual stream) or
+        "fp32" (the reference's default arithmetic: every operand f32, csrc/f32path.hip -- the mode the 1e-4 parity gates
+        of SURVEY 8d are stated for; an order of magnitude slower, kept for verification)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision {precision!r}: 'bf16' or 'fp32'")
+        fp32 = precision == "fp32"
+        act = f32 if fp32 else bf16
+        self.precision = precision
         dev = torch.device(device)
         self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
         D = ARCHS[arch]["embed_dim"]
@@ -883,12 +898,12 @@ class SupervisedEngine:
         # updated by the same fused optimizer pass (train.py:1080-1081)
         self.ema_decay = model_ema_decay
         self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=model_ema_decay is not None)
-        self.W = Weights(self.arena, "")
-        self.Wema = Weights(self.arena, "", teacher=True) if model_ema_decay is not None else None
-        self.vit = VitRunner(arch, img_size, dev)
-        self.grp = VitGroup(arch, [(batch, img_size)], img_size, dev, save=True)
+        self.W = Weights(self.arena, "", fp32=fp32)
+        self.Wema = Weights(self.arena, "", teacher=True, fp32=fp32) if model_ema_decay is not None else None
+        self.vit = VitRunner(arch, img_size, dev, fp32=fp32)
+        self.grp = VitGroup(arch, [(batch, img_size)], img_size, dev, save=True, act=act)
         e = lambda shape, dt: _empty(shape, dt, dev)
-        self.feats, self.dfeats = e((batch, D), bf16), e((batch, D), bf16)
+        self.feats, self.dfeats = e((batch, D), act), e((batch, D), act)
         self.logits, self.dlogits, self.prob = e((batch, num_classes), f32), e((batch, num_classes), f32), e((batch, num_classes), f32)
         self.loss = torch.zeros(1, dtype=f32, device=dev)
         self.ones = torch.ones(batch, dtype=f32, device=dev)

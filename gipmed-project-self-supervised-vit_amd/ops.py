@@ -20,6 +20,15 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _sfx(t: torch.Tensor) -> str:
+    """Entry-point suffix of the fp32 operand mode: chosen by the dtype of the buffer that is bf16 on the training path."""
+    if t.dtype == f32:
+        return "_f32"
+    if t.dtype != bf16:
+        raise TypeError(f"expected a bf16 (training path) or f32 (fp32 parity mode) tensor, got {t.dtype}")
+    return ""
+
+
 def _chk(t: torch.Tensor, dtype, name: str):
     if t.dtype != dtype or not t.is_cuda:
         raise TypeError(f"{name}: expected a {dtype} device tensor, got {t.dtype} on {t.device}")
@@ -64,7 +73,7 @@ def patchify(tiles_u8: torch.Tensor, windows: Sequence[Sequence[int]], crop: int
     if fill is not None:        # f32 [n_tiles, 8] device: normalised fill boxes (Cutout after Normalize, MeanPixelRegularization)
         assert fill.is_cuda and fill.dtype == f32 and fill.shape == (n_tiles, 8) and fill.is_contiguous()
         a.fill = fill.data_ptr()
-    L.call("gv_patchify", a, _stream())
+    L.call("gv_patchify" + _sfx(out), a, _stream())
     return out
 
 
@@ -92,7 +101,7 @@ def layernorm_fwd(x, gamma, beta, rows: int, D: int, x_stride: Optional[int] = N
     rstd = torch.empty(rows, dtype=f32, device=dev) if rstd is None else rstd
     a = L.gv_layernorm_fwd_args(x.data_ptr(), D if x_stride is None else x_stride, gamma.data_ptr(), beta.data_ptr(),
                                 y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, eps)
-    L.call("gv_layernorm_fwd", a, _stream())
+    L.call("gv_layernorm_fwd" + _sfx(y), a, _stream())
     return y, mean, rstd
 
 
@@ -102,7 +111,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, g, gb, partials, rows: int, D: int, 
     a = L.gv_layernorm_bwd_args(dy.data_ptr(), x.data_ptr(), D if x_stride is None else x_stride, mean.data_ptr(),
                                 rstd.data_ptr(), gamma.data_ptr(), g.data_ptr(), D if g_stride is None else g_stride,
                                 _p(gb), D if gb_stride is None else gb_stride, partials.data_ptr(), rows, D, int(g_init), _p(gb_scale))
-    L.call("gv_layernorm_bwd", a, _stream())
+    if gb is not None and gb.dtype != dy.dtype:
+        raise TypeError(f"layernorm_bwd: dy is {dy.dtype} but gb is {gb.dtype}")
+    L.call("gv_layernorm_bwd" + _sfx(dy), a, _stream())
 
 
 def colsum_finalize(partials, n_blocks: int, n_which: int, which: int, C: int, out, accumulate: bool):
@@ -136,7 +147,11 @@ def linear(A, B, C, M: int, N: int, K: int, *, trans_a=False, trans_b=False, epi
     a.pos, a.P, a.alpha, a.colsum_a, a.row_scale = _p(pos), P, alpha, _p(colsum_a), _p(row_scale)
     if workspace is not None:
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
-    L.call("gv_linear", a, _stream())
+    if A.dtype == f32:      # fp32 operand mode: A, B, C and the aux buffers are all f32
+        for t in (B, C, aux_in, aux_out):
+            if t is not None and t.dtype != f32:
+                raise TypeError(f"linear: f32 A with a {t.dtype} operand (the fp32 mode is f32 throughout)")
+    L.call("gv_linear" + _sfx(A), a, _stream())
     return C
 
 
@@ -188,17 +203,21 @@ def linear_dw_group(problems, K: int, workspace):
 
 def attention_fwd(qkv, n_img: int, N: int, H: int, scale: float, o=None, lse=None):
     dev = qkv.device
-    o = torch.empty(n_img * N, H * 64, dtype=bf16, device=dev) if o is None else o
+    o = torch.empty(n_img * N, H * 64, dtype=qkv.dtype, device=dev) if o is None else o
     lse = torch.empty(n_img, H, N, dtype=f32, device=dev) if lse is None else lse
     a = L.gv_attention_fwd_args(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), n_img, N, H, scale)
-    L.call("gv_attention_fwd", a, _stream())
+    if o.dtype != qkv.dtype:
+        raise TypeError(f"attention_fwd: qkv is {qkv.dtype} but o is {o.dtype}")
+    L.call("gv_attention_fwd" + _sfx(qkv), a, _stream())
     return o, lse
 
 
 def attention_bwd(qkv, o, d_o, lse, n_img: int, N: int, H: int, scale: float, dqkv=None):
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
     a = L.gv_attention_bwd_args(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), n_img, N, H, scale)
-    L.call("gv_attention_bwd", a, _stream())
+    if not (o.dtype == d_o.dtype == dqkv.dtype == qkv.dtype):
+        raise TypeError("attention_bwd: qkv / o / d_o / dqkv must share one dtype")
+    L.call("gv_attention_bwd" + _sfx(qkv), a, _stream())
     return dqkv
 
 
@@ -213,7 +232,7 @@ def cls_rows(x, cls, pos, n_img: int, N: int, D: int):
 
 def tokens_bwd(g, gpatch, dpos, dcls, n_img: int, N: int, D: int, accumulate: bool):
     a = L.gv_tokens_bwd_args(g.data_ptr(), gpatch.data_ptr(), dpos.data_ptr(), _p(dcls), n_img, N, D, int(accumulate))
-    L.call("gv_tokens_bwd", a, _stream())
+    L.call("gv_tokens_bwd" + _sfx(gpatch), a, _stream())
 
 
 def small_matmul(A, B, C, M: int, N: int, K: int, *, sam, sak, sbk, sbn, ldc=None, bias=None, accumulate=False):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 5
+#define GV_ABI_VERSION 6
 enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
        GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
@@ -433,6 +433,21 @@ typedef struct {
     int32_t mode;
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
+
+/* ---- fp32 operand mode (SURVEY 8d fp32 column; the reference's default arithmetic, train.py without --amp) -------
+ * The same entry points with EVERY bf16 buffer of the argument struct read / written as f32 instead (activations,
+ * GEMM operands incl. the weights, aux_in / aux_out, attention q/k/v/o/dO/dqkv, LayerNorm y / dy / gb, patch rows);
+ * f32 fields keep their meaning.  Linear: v_mfma_f32_16x16x4_f32, any M / N / K, exact erf GELU and GELU', c_is_f32
+ * must be 1, workspace ignored (no split-K), colsum_a without atomics.  Attention: N <= 260.  A parity mode: it holds
+ * the 1e-4 logits / loss and 1e-3 gradient-norm gates against the fp32 oracle (tests/test_fp32_gpu.py); the
+ * training path stays bf16.                                                                                        */
+int gv_linear_f32(const gv_linear_args* a, void* stream);
+int gv_attention_fwd_f32(const gv_attention_fwd_args* a, void* stream);
+int gv_attention_bwd_f32(const gv_attention_bwd_args* a, void* stream);
+int gv_layernorm_fwd_f32(const gv_layernorm_fwd_args* a, void* stream);
+int gv_layernorm_bwd_f32(const gv_layernorm_bwd_args* a, void* stream);
+int gv_patchify_f32(const gv_patchify_args* a, void* stream);
+int gv_tokens_bwd_f32(const gv_tokens_bwd_args* a, void* stream);
 
 #ifdef __cplusplus
 }
