@@ -104,7 +104,8 @@ ENTRY_POINTS = {
     # fp32 operand mode: the same structs with every bf16 buffer read / written as f32
     "gv_linear_f32": gv_linear_args, "gv_attention_fwd_f32": gv_attention_fwd_args, "gv_attention_bwd_f32": gv_attention_bwd_args,
     "gv_layernorm_fwd_f32": gv_layernorm_fwd_args, "gv_layernorm_bwd_f32": gv_layernorm_bwd_args, "gv_patchify_f32": gv_patchify_args,
-    "gv_tokens_bwd_f32": gv_tokens_bwd_args,
+    "gv_tokens_bwd_f32": gv_tokens_bwd_args, "gv_l2norm_fwd_f32": gv_l2norm_fwd_args, "gv_l2norm_bwd_f32": gv_l2norm_bwd_args,
+    "gv_weightnorm_fwd_f32": gv_weightnorm_fwd_args, "gv_dino_loss_f32": gv_dino_loss_args,
 }
 PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read",
                  "gv_linear_ln_blocks")

@@ -13,7 +13,13 @@ namespace {
 
 constexpr int MAXV = 16, MAXG = 4;
 
+// DT: element type of the student-logit gradient -- bf16 on the training path (fast exp / log: their ~1e-6 relative
+// error is far below the bf16 rounding of the result); float in the fp32 operand mode, which uses expf / logf
+template <typename DT> __device__ __forceinline__ float ex(float x) { if constexpr (sizeof(DT) == 4) return expf(x); else return __expf(x); }
+template <typename DT> __device__ __forceinline__ float lg(float x) { if constexpr (sizeof(DT) == 4) return logf(x); else return __logf(x); }
+
 // one block per logits row: running max / sum-exp of the temperature-scaled row
+template <typename DT>
 __global__ __launch_bounds__(256) void row_stats_kernel(gv_dino_loss_args a) {
     __shared__ float red_m[4], red_s[4];
     const int row = blockIdx.x;
@@ -28,11 +34,11 @@ __global__ __launch_bounds__(256) void row_stats_kernel(gv_dino_loss_args a) {
         if (teacher) { f32x4 c = *(const f32x4*)(a.center + k); v -= c; }
         v *= inv_t;
         const float lm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        if (lm > m) { s *= __expf(m - lm); m = lm; }
-        s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+        if (lm > m) { s *= ex<DT>(m - lm); m = lm; }
+        s += ex<DT>(v[0] - m) + ex<DT>(v[1] - m) + ex<DT>(v[2] - m) + ex<DT>(v[3] - m);
     }
     const float wm = wave_max(m);
-    s = (m == -INFINITY) ? 0.f : s * __expf(m - wm);   // idle lanes when K < 1024
+    s = (m == -INFINITY) ? 0.f : s * ex<DT>(m - wm);   // idle lanes when K < 1024
     s = wave_sum(s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red_m[wave] = wm; red_s[wave] = s; }
@@ -40,13 +46,14 @@ __global__ __launch_bounds__(256) void row_stats_kernel(gv_dino_loss_args a) {
     if (threadIdx.x == 0) {
         const float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
         float S = 0.f;
-        for (int w = 0; w < 4; ++w) S += red_s[w] * __expf(red_m[w] - M);
+        for (int w = 0; w < 4; ++w) S += red_s[w] * ex<DT>(red_m[w] - M);
         a.workspace[2 * row] = M;
-        a.workspace[2 * row + 1] = __logf(S);
+        a.workspace[2 * row + 1] = lg<DT>(S);
     }
 }
 
 // grid (K/256, bsplit); thread = one class k, loops over its slice of the batch
+template <typename DT>
 __global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int b_per, float coef, float inv_pairs_b) {
     __shared__ float red[4];
     if (a.hyper) {   // coef was built with the by-value student temperature
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int
                     const int row = ns + iq * B + b;
                     const float raw = a.teacher[(long)(iq * B + b) * K + k];
                     csum += raw;
-                    t[iq] = __expf((raw - c) * inv_tt - a.workspace[2 * row] - a.workspace[2 * row + 1]);
+                    t[iq] = ex<DT>((raw - c) * inv_tt - a.workspace[2 * row] - a.workspace[2 * row + 1]);
                     tsum += t[iq];
                 } else t[iq] = 0.f;
             }
@@ -78,11 +85,11 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int
                 const int row = v * B + b;
                 const float s = a.student[(long)row * K + k] * inv_ts;
                 const float logp = s - a.workspace[2 * row] - a.workspace[2 * row + 1];
-                const float p = __expf(logp);
+                const float p = ex<DT>(logp);
                 float ts = tsum, nv = (float)G;
                 if (v < G) { ts -= (v == 0 ? t[0] : v == 1 ? t[1] : v == 2 ? t[2] : t[3]); nv -= 1.f; }
                 loss -= ts * logp;
-                ((bf16*)a.dstudent)[(long)row * K + k] = (bf16)(coef * (nv * p - ts));
+                ((DT*)a.dstudent)[(long)row * K + k] = (DT)(coef * (nv * p - ts));
             }
         }
         atomicAdd(a.center_sum + k, csum);
@@ -93,9 +100,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int
     if (threadIdx.x == 0) atomicAdd(a.loss, (red[0] + red[1] + red[2] + red[3]) * inv_pairs_b);
 }
 
-}  // namespace
-
-extern "C" int gv_dino_loss(const gv_dino_loss_args* a, void* stream) {
+template <typename DT> int dino_loss_launch(const gv_dino_loss_args* a, void* stream) {
     GV_REQUIRE(a && a->student && a->teacher && a->center && a->dstudent && a->loss && a->center_sum && a->workspace,
                GV_E_NULL, "gv_dino_loss: null pointer");
     GV_REQUIRE(a->B > 0 && a->V >= 2 && a->V <= MAXV && a->G >= 1 && a->G <= MAXG && a->G <= a->V, GV_E_SHAPE,
@@ -107,7 +112,7 @@ extern "C" int gv_dino_loss(const gv_dino_loss_args* a, void* stream) {
     if (e == hipSuccess) e = hipMemsetAsync(a->center_sum, 0, sizeof(float) * a->K, s);
     if (e != hipSuccess) GV_FAIL((int)e, "gv_dino_loss: memset failed: %s", hipGetErrorString(e));
     const int rows = (a->V + a->G) * a->B;
-    hipLaunchKernelGGL(row_stats_kernel, dim3(rows), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(row_stats_kernel<DT>, dim3(rows), dim3(256), 0, s, *a);
     GV_LAUNCH_CHECK("gv_dino_loss(row_stats)");
     const int kblocks = (a->K + 255) / 256;
     int bsplit = (1024 + kblocks - 1) / kblocks;
@@ -119,7 +124,12 @@ extern "C" int gv_dino_loss(const gv_dino_loss_args* a, void* stream) {
     const float inv_pairs_b = 1.0f / ((float)n_pairs * (float)a->B);
     const float gs = a->grad_scale == 0.f ? 1.f : a->grad_scale;
     const float coef = gs * inv_pairs_b / a->student_temp;
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(kblocks, bsplit), dim3(256), 0, s, *a, b_per, coef, inv_pairs_b);
+    hipLaunchKernelGGL(loss_grad_kernel<DT>, dim3(kblocks, bsplit), dim3(256), 0, s, *a, b_per, coef, inv_pairs_b);
     GV_LAUNCH_CHECK("gv_dino_loss(loss_grad)");
     return GV_OK;
 }
+
+}  // namespace
+
+extern "C" int gv_dino_loss(const gv_dino_loss_args* a, void* stream) { return dino_loss_launch<bf16>(a, stream); }
+extern "C" int gv_dino_loss_f32(const gv_dino_loss_args* a, void* stream) { return dino_loss_launch<float>(a, stream); }

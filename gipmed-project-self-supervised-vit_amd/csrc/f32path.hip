@@ -8,6 +8,7 @@
 // It is a PARITY mode: correct by construction, full f32 everywhere, no split-K, no fused LayerNorm; its speed is
 // bounded by the f32 MFMA rate (1/16 of bf16) and nobody trains in it.  The training path stays bf16.
 #include "gv_common.h"
+#include "timing.h"
 #include <math.h>
 
 namespace {
@@ -23,6 +24,8 @@ constexpr int LBM = 128, LBN = 128, LBK = 16, LLD = 144;
 struct LinP {
     gv_linear_args a;
     int vec_a, vec_b;     // 16-byte loads allowed (base and leading dimension aligned)
+    int k_per;            // split-K (pure ACCUM launches only): blockIdx.z reduces k in [z * k_per, (z + 1) * k_per) and adds its
+                          // partial tile into C with f32 atomics; = K when the launch is not split
 };
 
 // one [128 rows x 16 k] operand tile: element (r, k) at X[r*ld + k] (kc) or X[k*ld + r] (!kc)
@@ -73,7 +76,9 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinP p) {
     __shared__ float As[LBK * LLD], Bs[LBK * LLD];
     const float* A = (const float*)a.A;
     const float* B = (const float*)a.B;
-    const int M = a.M, N = a.N, K = a.K;
+    const int M = a.M, N = a.N;
+    const int kb = blockIdx.z * p.k_per, K = min(a.K, kb + p.k_per);      // this workgroup's k range is [kb, K)
+    const bool split = gridDim.z > 1;
     const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
     const bool kcA = !a.trans_a, kcB = !a.trans_b;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wm = wave >> 1, wn = wave & 1, li = lane & 15, g = lane >> 4;
@@ -85,9 +90,9 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinP p) {
     const bool do_cs = a.colsum_a != nullptr && blockIdx.x == 0;
     float cs = 0.f;
     f32x4 ra[2], rb[2];
-    tile_load(A, a.lda, kcA, p.vec_a, m0, M, 0, K, ra);
-    tile_load(B, a.ldb, kcB, p.vec_b, n0, N, 0, K, rb);
-    for (int k0 = 0; k0 < K; k0 += LBK) {
+    tile_load(A, a.lda, kcA, p.vec_a, m0, M, kb, K, ra);
+    tile_load(B, a.ldb, kcB, p.vec_b, n0, N, kb, K, rb);
+    for (int k0 = kb; k0 < K; k0 += LBK) {
         __syncthreads();                       // the previous step's fragment reads are done
         tile_store(As, kcA, ra);
         tile_store(Bs, kcB, rb);
@@ -113,7 +118,25 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinP p) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (do_cs && threadIdx.x < LBM && m0 + (int)threadIdx.x < M) a.colsum_a[m0 + threadIdx.x] += cs;   // one workgroup per row block: no atomics
+    if (do_cs && threadIdx.x < LBM && m0 + (int)threadIdx.x < M) {
+        if (split) atomicAdd(a.colsum_a + m0 + threadIdx.x, cs);
+        else a.colsum_a[m0 + threadIdx.x] += cs;        // one workgroup per row block: no atomics
+    }
+    if (split) {       // pure ACCUM (checked on the host): partial tiles meet in C
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + g * 4 + r;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + li;
+                    if (n < N) atomicAdd((float*)a.C + (long)m * a.ldc + n, acc[i][j][r] * (a.alpha == 0.f ? 1.f : a.alpha));
+                }
+            }
+        return;
+    }
 
     // epilogue, in gv_linear's documented order; accumulator fragment: row 4g + r, column li
     const int e = a.epilogue;
@@ -361,7 +384,29 @@ extern "C" int gv_linear_f32(const gv_linear_args* a, void* stream) {
     p.vec_b = gv_aligned(a->B, 16) && a->ldb % 4 == 0;
     const long tm = (a->M + LBM - 1) / LBM, tn = (a->N + LBN - 1) / LBN;
     GV_REQUIRE(tm < 65536, GV_E_SHAPE, "gv_linear_f32: M=%d too large", a->M);
-    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)tn, (unsigned)tm), dim3(256), 0, (hipStream_t)stream, p);
+    // Split K when the output grid alone leaves most of the 256 CUs idle (weight gradients: a handful of tiles reduced over
+    // every token row; the DINO head's dX over 65536 classes).  Needs pure ACCUM semantics -- C already holds the value the
+    // partial sums are added to -- and costs the bitwise run-to-run reproducibility of those outputs (f32 atomics).
+    int S = 1;
+    if (e == GV_EPI_ACCUM && tm * tn < 256) {
+        const long want = 512 / (tm * tn), maxs = a->K / 256;          // at least 256 deep per slice
+        S = (int)(want < maxs ? want : maxs);
+        if (S < 1) S = 1;
+    }
+    const int ksteps = (a->K + LBK - 1) / LBK, per = (ksteps + S - 1) / S;
+    p.k_per = per * LBK;
+    S = (ksteps + per - 1) / per;
+    int th = -1;
+    if (gvtime::enabled()) {       // algorithmic bytes: every operand read once, every output written once, all f32
+        const double mn = (double)a->M * a->N;
+        double bytes = 4.0 * ((double)a->M * a->K + (double)a->N * a->K) + 4.0 * mn;
+        if (e & (GV_EPI_RESID | GV_EPI_ACCUM)) bytes += 4.0 * mn;
+        if (e & GV_EPI_DGELU) bytes += 4.0 * mn;
+        if (e & GV_EPI_SAVE_PRE) bytes += 4.0 * mn;
+        th = gvtime::begin("linear_f32_kernel", 2.0 * a->M * a->N * a->K, bytes, (hipStream_t)stream);
+    }
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)tn, (unsigned)tm, (unsigned)S), dim3(256), 0, (hipStream_t)stream, p);
+    gvtime::end(th, (hipStream_t)stream);
     GV_LAUNCH_CHECK("gv_linear_f32");
     return GV_OK;
 }

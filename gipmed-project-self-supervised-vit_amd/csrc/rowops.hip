@@ -56,7 +56,15 @@ __global__ void small_matmul_kernel(gv_small_matmul_args a) {
     }
 }
 
+// four elements of a buffer that is bf16 on the training path and f32 in the fp32 operand mode
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 ld4<bf16>(const bf16* p) { const bf16x4 v = *(const bf16x4*)p; return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void st4(bf16* p, f32x4 v) { *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
+
 // one wave per row, C = 256 (DINOHead bottleneck): 4 columns per lane
+template <typename HT>
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(gv_l2norm_fwd_args a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
@@ -64,34 +72,35 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(gv_l2norm_fwd_args a) {
     float s = 0.f;
     for (int c = lane * 4; c < a.C; c += 256) { f32x4 v = *(const f32x4*)(x + c); s += v[0]*v[0] + v[1]*v[1] + v[2]*v[2] + v[3]*v[3]; }
     const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
-    bf16* y = (bf16*)a.y + (long)row * a.C;
+    HT* y = (HT*)a.y + (long)row * a.C;
     for (int c = lane * 4; c < a.C; c += 256) {
         f32x4 v = *(const f32x4*)(x + c);
-        *(bf16x4*)(y + c) = bf16x4{(bf16)(v[0]*inv), (bf16)(v[1]*inv), (bf16)(v[2]*inv), (bf16)(v[3]*inv)};
+        st4(y + c, f32x4{v[0]*inv, v[1]*inv, v[2]*inv, v[3]*inv});
     }
     if (lane == 0) a.inv_norm[row] = inv;
 }
 
+template <typename HT>
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(gv_l2norm_bwd_args a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const float* dy = a.dy + (long)row * a.C;
-    const bf16* y = (const bf16*)a.y + (long)row * a.C;
+    const HT* y = (const HT*)a.y + (long)row * a.C;
     float s = 0.f;
     for (int c = lane * 4; c < a.C; c += 256) {
-        f32x4 d = *(const f32x4*)(dy + c); bf16x4 yy = *(const bf16x4*)(y + c);
-        s += d[0]*(float)yy[0] + d[1]*(float)yy[1] + d[2]*(float)yy[2] + d[3]*(float)yy[3];
+        f32x4 d = *(const f32x4*)(dy + c); f32x4 yy = ld4(y + c);
+        s += d[0]*yy[0] + d[1]*yy[1] + d[2]*yy[2] + d[3]*yy[3];
     }
     s = wave_sum(s);
     const float inv = a.inv_norm[row];
-    bf16* dx = (bf16*)a.dx + (long)row * a.C;
+    HT* dx = (HT*)a.dx + (long)row * a.C;
     for (int c = lane * 4; c < a.C; c += 256) {
-        f32x4 d = *(const f32x4*)(dy + c); bf16x4 yy = *(const bf16x4*)(y + c);
-        *(bf16x4*)(dx + c) = bf16x4{(bf16)((d[0] - (float)yy[0]*s)*inv), (bf16)((d[1] - (float)yy[1]*s)*inv),
-                                    (bf16)((d[2] - (float)yy[2]*s)*inv), (bf16)((d[3] - (float)yy[3]*s)*inv)};
+        f32x4 d = *(const f32x4*)(dy + c); f32x4 yy = ld4(y + c);
+        st4(dx + c, f32x4{(d[0] - yy[0]*s)*inv, (d[1] - yy[1]*s)*inv, (d[2] - yy[2]*s)*inv, (d[3] - yy[3]*s)*inv});
     }
 }
 
+template <typename HT>
 __global__ __launch_bounds__(256) void weightnorm_fwd_kernel(gv_weightnorm_fwd_args a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
@@ -99,10 +108,10 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_kernel(gv_weightnorm_fwd_a
     float s = 0.f;
     for (int c = lane * 4; c < a.C; c += 256) { f32x4 x = *(const f32x4*)(v + c); s += x[0]*x[0] + x[1]*x[1] + x[2]*x[2] + x[3]*x[3]; }
     const float sc = a.g[row] / sqrtf(wave_sum(s));
-    bf16* w = (bf16*)a.w + (long)row * a.C;
+    HT* w = (HT*)a.w + (long)row * a.C;
     for (int c = lane * 4; c < a.C; c += 256) {
         f32x4 x = *(const f32x4*)(v + c);
-        *(bf16x4*)(w + c) = bf16x4{(bf16)(x[0]*sc), (bf16)(x[1]*sc), (bf16)(x[2]*sc), (bf16)(x[3]*sc)};
+        st4(w + c, f32x4{x[0]*sc, x[1]*sc, x[2]*sc, x[3]*sc});
     }
 }
 
@@ -265,15 +274,27 @@ extern "C" int gv_small_matmul(const gv_small_matmul_args* a, void* stream) {
 
 extern "C" int gv_l2norm_fwd(const gv_l2norm_fwd_args* a, void* stream) {
     GV_REQUIRE(a && a->x && a->y && a->inv_norm, GV_E_NULL, "gv_l2norm_fwd: null pointer");
-    GV_ROW_LAUNCH(l2norm_fwd_kernel, a, "gv_l2norm_fwd")
+    GV_ROW_LAUNCH(l2norm_fwd_kernel<bf16>, a, "gv_l2norm_fwd")
 }
 extern "C" int gv_l2norm_bwd(const gv_l2norm_bwd_args* a, void* stream) {
     GV_REQUIRE(a && a->dy && a->y && a->inv_norm && a->dx, GV_E_NULL, "gv_l2norm_bwd: null pointer");
-    GV_ROW_LAUNCH(l2norm_bwd_kernel, a, "gv_l2norm_bwd")
+    GV_ROW_LAUNCH(l2norm_bwd_kernel<bf16>, a, "gv_l2norm_bwd")
 }
 extern "C" int gv_weightnorm_fwd(const gv_weightnorm_fwd_args* a, void* stream) {
     GV_REQUIRE(a && a->v && a->g && a->w, GV_E_NULL, "gv_weightnorm_fwd: null pointer");
-    GV_ROW_LAUNCH(weightnorm_fwd_kernel, a, "gv_weightnorm_fwd")
+    GV_ROW_LAUNCH(weightnorm_fwd_kernel<bf16>, a, "gv_weightnorm_fwd")
+}
+extern "C" int gv_l2norm_fwd_f32(const gv_l2norm_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->x && a->y && a->inv_norm, GV_E_NULL, "gv_l2norm_fwd: null pointer");
+    GV_ROW_LAUNCH(l2norm_fwd_kernel<float>, a, "gv_l2norm_fwd_f32")
+}
+extern "C" int gv_l2norm_bwd_f32(const gv_l2norm_bwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->dy && a->y && a->inv_norm && a->dx, GV_E_NULL, "gv_l2norm_bwd: null pointer");
+    GV_ROW_LAUNCH(l2norm_bwd_kernel<float>, a, "gv_l2norm_bwd_f32")
+}
+extern "C" int gv_weightnorm_fwd_f32(const gv_weightnorm_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->v && a->g && a->w, GV_E_NULL, "gv_weightnorm_fwd: null pointer");
+    GV_ROW_LAUNCH(weightnorm_fwd_kernel<float>, a, "gv_weightnorm_fwd_f32")
 }
 extern "C" int gv_weightnorm_bwd(const gv_weightnorm_bwd_args* a, void* stream) {
     GV_REQUIRE(a && a->dw && a->v && a->g && a->dv, GV_E_NULL, "gv_weightnorm_bwd: null pointer");

@@ -533,19 +533,19 @@ class VitRunner:
 # DINO head (vit.pyc@L296-330) forward / backward over R rows
 # --------------------------------------------------------------------------- #
 class HeadBuffers:
-    def __init__(self, R: int, D: int, K: int, hidden: int, bott: int, device, save: bool):
+    def __init__(self, R: int, D: int, K: int, hidden: int, bott: int, device, save: bool, act=bf16):
         e = lambda shape, dt: _empty(shape, dt, device)
         self.R = R
-        self.feats = e((R, D), bf16)
-        self.h1p, self.h1 = e((R, hidden), bf16), e((R, hidden), bf16)
-        self.h2p, self.h2 = e((R, hidden), bf16), e((R, hidden), bf16)
-        self.z, self.zn, self.inv = e((R, bott), f32), e((R, bott), bf16), e((R,), f32)
+        self.feats = e((R, D), act)
+        self.h1p, self.h1 = e((R, hidden), act), e((R, hidden), act)
+        self.h2p, self.h2 = e((R, hidden), act), e((R, hidden), act)
+        self.z, self.zn, self.inv = e((R, bott), f32), e((R, bott), act), e((R,), f32)
         self.logits = e((R, K), f32)
         if save:
-            self.dlogits = e((R, K), bf16)
-            self.dzn, self.dz = e((R, bott), f32), e((R, bott), bf16)
-            self.dh2, self.dh1 = e((R, hidden), bf16), e((R, hidden), bf16)
-            self.dfeats = e((R, D), bf16)
+            self.dlogits = e((R, K), act)
+            self.dzn, self.dz = e((R, bott), f32), e((R, bott), act)
+            self.dh2, self.dh1 = e((R, hidden), act), e((R, hidden), act)
+            self.dfeats = e((R, D), act)
             self.dwn = e((K, bott), f32)
 
 
@@ -625,7 +625,14 @@ class DinoEngine:
     def __init__(self, arch="vit_small", img_size=224, out_dim=65536, batch=64, tile=256, n_global=2, n_local=8,
                  gsize=224, lsize=96, hidden=2048, bottleneck=256, lr=5e-4, weight_decay=0.04, betas=(0.9, 0.999), eps=1e-8,
                  momentum_teacher=0.996, student_temp=0.1, teacher_temp=0.04, center_momentum=0.9, clip_grad: float = 0.0,
-                 mean=MEAN_RON, std=STD_RON, windows=None, device="cuda:0", reducer=None):
+                 mean=MEAN_RON, std=STD_RON, windows=None, device="cuda:0", reducer=None, precision: str = "bf16"):
+        """``precision``: "bf16" (the training path) or "fp32" (every GEMM / attention operand, the head activations, the
+        weight-normalised prototype matrix and the logit gradient in f32 -- the verification mode of SURVEY 8d's fp32 column)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision {precision!r}: 'bf16' or 'fp32'")
+        fp32 = precision == "fp32"
+        act = f32 if fp32 else bf16
+        self.precision = precision
         dev = torch.device(device)
         self.dev, self.arch, self.B, self.tile = dev, arch, batch, tile
         D = ARCHS[arch]["embed_dim"]
@@ -639,19 +646,19 @@ class DinoEngine:
         specs = OrderedDict(("backbone." + k, v) for k, v in vit_param_specs(arch, img_size, 0).items())
         specs.update(("head." + k, v) for k, v in dino_head_specs(D, out_dim, hidden, bottleneck).items())
         self.arena = Arena(specs, dev, teacher=True)
-        self.sW, self.tW = Weights(self.arena, "backbone."), Weights(self.arena, "backbone.", teacher=True)
-        self.sH, self.tH = Weights(self.arena, "head."), Weights(self.arena, "head.", teacher=True)
-        self.vit = VitRunner(arch, img_size, dev)
+        self.sW, self.tW = Weights(self.arena, "backbone.", fp32=fp32), Weights(self.arena, "backbone.", teacher=True, fp32=fp32)
+        self.sH, self.tH = Weights(self.arena, "head.", fp32=fp32), Weights(self.arena, "head.", teacher=True, fp32=fp32)
+        self.vit = VitRunner(arch, img_size, dev, fp32=fp32)
         self.head = HeadRunner(D, out_dim, hidden, bottleneck, dev)
         B = batch
         segs = [(n_global * B, gsize)] + ([(n_local * B, lsize)] if n_local else [])
-        self.g_stu = VitGroup(arch, segs, img_size, dev, save=True)            # all student crops, tokens concatenated
-        self.g_teach = VitGroup(arch, [(n_global * B, gsize)], img_size, dev, save=False)
+        self.g_stu = VitGroup(arch, segs, img_size, dev, save=True, act=act)   # all student crops, tokens concatenated
+        self.g_teach = VitGroup(arch, [(n_global * B, gsize)], img_size, dev, save=False, act=act)
         self.s_wins = [self.gwins] + ([self.lwins] if n_local else [])
-        self.hb_s = HeadBuffers(self.V * B, D, out_dim, hidden, bottleneck, dev, save=True)
-        self.hb_t = HeadBuffers(n_global * B, D, out_dim, hidden, bottleneck, dev, save=False)
-        self.wn_s = _empty((out_dim, bottleneck), bf16, dev)
-        self.wn_t = _empty((out_dim, bottleneck), bf16, dev)
+        self.hb_s = HeadBuffers(self.V * B, D, out_dim, hidden, bottleneck, dev, save=True, act=act)
+        self.hb_t = HeadBuffers(n_global * B, D, out_dim, hidden, bottleneck, dev, save=False, act=act)
+        self.wn_s = _empty((out_dim, bottleneck), act, dev)
+        self.wn_t = _empty((out_dim, bottleneck), act, dev)
         self.center = torch.zeros(out_dim, dtype=f32, device=dev)
         self.center_sum = torch.zeros(out_dim, dtype=f32, device=dev)
         self.loss = torch.zeros(1, dtype=f32, device=dev)
@@ -1001,20 +1008,25 @@ class FeatureExtractor:
     extractor then evaluates those live parameters instead of owning a copy (validation between epochs)."""
 
     def __init__(self, arch="vit_small", img_size=256, batch=256, num_classes=0, mean=MEAN_RON, std=STD_RON, device="cuda:0",
-                 weights: Optional[Weights] = None):
+                 weights: Optional[Weights] = None, precision: str = "bf16"):
+        """``precision``: as for the engines; with ``weights`` it follows the owning engine's mode."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision {precision!r}: 'bf16' or 'fp32'")
+        fp32 = weights.fp32 if weights is not None else precision == "fp32"
+        act = f32 if fp32 else bf16
         dev = torch.device(device)
         self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
         self.D = ARCHS[arch]["embed_dim"]
         self.mean, self.std = tuple(mean), tuple(std)
         if weights is None:
             self.arena = Arena(vit_param_specs(arch, img_size, num_classes), dev, teacher=False)
-            self.W = Weights(self.arena, "")
+            self.W = Weights(self.arena, "", fp32=fp32)
         else:
             self.arena, self.W = weights.a, weights
-        self.vit = VitRunner(arch, img_size, dev)
+        self.vit = VitRunner(arch, img_size, dev, fp32=fp32)
         self.vit.side = None                       # a forward-only pass has nothing to put on a side stream
-        self.grp = VitGroup(arch, [(batch, img_size)], img_size, dev, save=False)
-        self.feats = _empty((batch, self.D), bf16, dev)
+        self.grp = VitGroup(arch, [(batch, img_size)], img_size, dev, save=False, act=act)
+        self.feats = _empty((batch, self.D), act, dev)
         self.logits = _empty((batch, num_classes), f32, dev) if num_classes else None
         self._pad = None
 

@@ -151,6 +151,10 @@ def linear(A, B, C, M: int, N: int, K: int, *, trans_a=False, trans_b=False, epi
         for t in (B, C, aux_in, aux_out):
             if t is not None and t.dtype != f32:
                 raise TypeError(f"linear: f32 A with a {t.dtype} operand (the fp32 mode is f32 throughout)")
+    else:
+        for t in (B, aux_in, aux_out):
+            if t is not None and t.dtype != bf16:
+                raise TypeError(f"linear: bf16 A with a {t.dtype} operand")
     L.call("gv_linear" + _sfx(A), a, _stream())
     return C
 
@@ -243,15 +247,17 @@ def small_matmul(A, B, C, M: int, N: int, K: int, *, sam, sak, sbk, sbn, ldc=Non
 
 
 def l2norm_fwd(x, y, inv_norm, rows: int, C: int):
-    L.call("gv_l2norm_fwd", L.gv_l2norm_fwd_args(x.data_ptr(), y.data_ptr(), inv_norm.data_ptr(), rows, C), _stream())
+    L.call("gv_l2norm_fwd" + _sfx(y), L.gv_l2norm_fwd_args(x.data_ptr(), y.data_ptr(), inv_norm.data_ptr(), rows, C), _stream())
 
 
 def l2norm_bwd(dy, y, inv_norm, dx, rows: int, C: int):
-    L.call("gv_l2norm_bwd", L.gv_l2norm_bwd_args(dy.data_ptr(), y.data_ptr(), inv_norm.data_ptr(), dx.data_ptr(), rows, C), _stream())
+    if dx.dtype != y.dtype:
+        raise TypeError(f"l2norm_bwd: y is {y.dtype} but dx is {dx.dtype}")
+    L.call("gv_l2norm_bwd" + _sfx(y), L.gv_l2norm_bwd_args(dy.data_ptr(), y.data_ptr(), inv_norm.data_ptr(), dx.data_ptr(), rows, C), _stream())
 
 
 def weightnorm_fwd(v, g, w, rows: int, C: int):
-    L.call("gv_weightnorm_fwd", L.gv_weightnorm_fwd_args(v.data_ptr(), g.data_ptr(), w.data_ptr(), rows, C), _stream())
+    L.call("gv_weightnorm_fwd" + _sfx(w), L.gv_weightnorm_fwd_args(v.data_ptr(), g.data_ptr(), w.data_ptr(), rows, C), _stream())
 
 
 def weightnorm_bwd(dw, v, g, dv, dg, rows: int, C: int, accumulate: bool):
@@ -263,7 +269,7 @@ def dino_loss(student, teacher, center, dstudent, loss, center_sum, workspace, B
               student_temp: float, teacher_temp: float, grad_scale: float = 1.0, hyper=None):
     a = L.gv_dino_loss_args(student.data_ptr(), teacher.data_ptr(), center.data_ptr(), dstudent.data_ptr(), loss.data_ptr(),
                             center_sum.data_ptr(), workspace.data_ptr(), B, V, G, K, student_temp, teacher_temp, grad_scale, _p(hyper))
-    L.call("gv_dino_loss", a, _stream())
+    L.call("gv_dino_loss" + _sfx(dstudent), a, _stream())
 
 
 def center_update(center, center_sum, K: int, momentum: float, inv_rows: float):

@@ -23,6 +23,7 @@ from . import ops
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md, HBM3E
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense f32 MFMA (v_mfma_f32_16x16x4_f32): the fp32 operand mode's kernel
 
 
 def _traffic_for(kernel: str):
@@ -78,12 +79,13 @@ def dominant_kernel_roofline(step_fn, steps: int = 3, vit=None):
               "gbs": round(r["bytes"] / r["seconds"] / 1e9, 0)} for r in rows]
     d = rows[0]
     tf, gbs = d["flops"] / d["seconds"] / 1e12, d["bytes"] / d["seconds"] / 1e9
-    hbm_bound = d["bytes"] > 0 and d["flops"] / d["bytes"] < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS
+    peak_tf = PEAK_F32_MFMA_TFLOPS if "f32_kernel" in d["kernel"] else PEAK_BF16_TFLOPS
+    hbm_bound = d["bytes"] > 0 and d["flops"] / d["bytes"] < peak_tf * 1e3 / PEAK_HBM_GBS
     traffic, src = _traffic_for(d["kernel"])
     head = ({"bound": "hbm", "kernel": d["kernel"], "achieved": round(gbs, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
             if hbm_bound else
-            {"bound": "mfma", "kernel": d["kernel"], "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)})
-    return {**head, "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+            {"bound": "mfma", "kernel": d["kernel"], "achieved": round(tf, 1), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4)})
+    return {**head, "mfma_frac": round(tf / peak_tf, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
             "flop_per_byte": round(d["flops"] / d["bytes"], 1) if d["bytes"] > 0 else None,
             "avg_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 2),
             "traffic": traffic, "traffic_source": src,

@@ -438,9 +438,9 @@ int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
  * The same entry points with EVERY bf16 buffer of the argument struct read / written as f32 instead (activations,
  * GEMM operands incl. the weights, aux_in / aux_out, attention q/k/v/o/dO/dqkv, LayerNorm y / dy / gb, patch rows);
  * f32 fields keep their meaning.  Linear: v_mfma_f32_16x16x4_f32, any M / N / K, exact erf GELU and GELU', c_is_f32
- * must be 1, workspace ignored (no split-K), colsum_a without atomics.  Attention: N <= 260.  A parity mode: it holds
- * the 1e-4 logits / loss and 1e-3 gradient-norm gates against the fp32 oracle (tests/test_fp32_gpu.py); the
- * training path stays bf16.                                                                                        */
+ * must be 1, workspace ignored (pure-ACCUM launches with few output tiles split K through f32 atomics).
+ * Attention: N <= 260.  A parity mode: it holds the 1e-4 logits / loss and 1e-3 gradient-norm gates against the fp32
+ * oracle (tests/test_fp32_gpu.py); the training path stays bf16.                                                   */
 int gv_linear_f32(const gv_linear_args* a, void* stream);
 int gv_attention_fwd_f32(const gv_attention_fwd_args* a, void* stream);
 int gv_attention_bwd_f32(const gv_attention_bwd_args* a, void* stream);
@@ -448,6 +448,11 @@ int gv_layernorm_fwd_f32(const gv_layernorm_fwd_args* a, void* stream);
 int gv_layernorm_bwd_f32(const gv_layernorm_bwd_args* a, void* stream);
 int gv_patchify_f32(const gv_patchify_args* a, void* stream);
 int gv_tokens_bwd_f32(const gv_tokens_bwd_args* a, void* stream);
+/* DINO head: zn / dz (l2norm), the weight-normalised last-layer matrix, and the student-logit gradient as f32 */
+int gv_l2norm_fwd_f32(const gv_l2norm_fwd_args* a, void* stream);
+int gv_l2norm_bwd_f32(const gv_l2norm_bwd_args* a, void* stream);
+int gv_weightnorm_fwd_f32(const gv_weightnorm_fwd_args* a, void* stream);
+int gv_dino_loss_f32(const gv_dino_loss_args* a, void* stream);
 
 #ifdef __cplusplus
 }

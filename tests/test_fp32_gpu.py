@@ -72,6 +72,14 @@ def test_linear_f32_epilogues(dev):
     ops.linear(d(dY), d(X), Cg, M, N, K, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, colsum_a=cs)
     assert _rel(Cg, C0.double() + dY.double().t() @ X.double()) < 2e-6
     assert _rel(cs, cs0.double() + dY.double().sum(0)) < 2e-6
+    # ... and over many token rows, where the launch splits K and the partial tiles meet in C through f32 atomics
+    Kt, Md, Nd = 5000, 192, 390
+    dY, X = torch.randn(Kt, Md, generator=g), torch.randn(Kt, Nd, generator=g)
+    C0, cs0 = torch.randn(Md, Nd, generator=g), torch.randn(Md, generator=g)
+    Cg, cs = d(C0).clone(), d(cs0).clone()
+    ops.linear(d(dY), d(X), Cg, Md, Nd, Kt, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, colsum_a=cs)
+    assert _rel(Cg, C0.double() + dY.double().t() @ X.double()) < 2e-6
+    assert _rel(cs, cs0.double() + dY.double().sum(0)) < 2e-6
     # patch embedding: BIAS | POS (token-row remap past the CLS rows)
     n_img, P, Dm = 3, 16, 192
     patches, Wp, bp, pos = torch.randn(n_img * P, 768, generator=g), torch.randn(Dm, 768, generator=g) * 0.05, torch.randn(Dm, generator=g), torch.randn(P + 1, Dm, generator=g)
@@ -211,3 +219,51 @@ def test_fp32_supervised_wider_archs(dev, arch, img, B):
     eng.forward_backward(tiles.to(dev), tgt.to(dev))
     dl, dgn, worst = _gates(eng, loss_r, grads_r, logits_r)
     print(f"[fp32 {arch}] logits {dl:.2e}, grad-norm rel {dgn:.2e}, worst parameter gradient {worst[0]:.2e} ({worst[1]})")
+
+
+@gpu
+@pytest.mark.parametrize("arch,n_local,K", [("vit_tiny", 8, 4096), ("vit_tiny", 0, 4096), ("vit_small", 8, 2048)])
+def test_fp32_dino_step_gates(dev, arch, n_local, K):
+    """The DINO multi-crop step (2 x 224 global + 8 x 96 local crops of 256-px tiles, B = 2; ViT-T and the ViT-S of the
+    headline config) in the fp32 operand mode: teacher and student head outputs, loss, centre sum and every gradient at
+    the fp32 gates, then three optimizer + EMA + centre steps on the oracle's trajectory at 1e-4."""
+    from gipvit.engine import DinoEngine
+    from oracle import step_oracle as so
+    from oracle import vit_oracle as vo
+    B = 2
+    orc = so.DinoOracle(arch=arch, img_size=224, out_dim=K, seed=0, lr=5e-4, wd=0.04, n_local=n_local)
+    eng = DinoEngine(arch=arch, img_size=224, out_dim=K, batch=B, n_local=n_local, lr=5e-4, weight_decay=0.04, device=dev, precision="fp32")
+    assert eng.hb_s.dlogits.dtype == f32 and eng.wn_s.dtype == f32 and eng.g_stu.qkv[0].dtype == f32
+    eng.load_state(orc.p, orc.hp)
+    c = 0.05 * torch.randn(1, K, generator=torch.Generator().manual_seed(3))
+    orc.center = c.clone(); eng.center.copy_(c[0])
+    tiles = vo.synth_tiles(B, 256, seed=1234)
+    loss_r, grads_r, s_out, t_out, bsum = orc.forward_backward(tiles)
+    eng.set_hyper()
+    eng.forward_backward(tiles.to(dev))
+    torch.cuda.synchronize()
+    for got, ref, nm in ((eng.hb_t.logits, t_out, "teacher"), (eng.hb_s.logits, s_out, "student")):
+        err = float((got.cpu() - ref).abs().max())
+        assert err <= LOGIT_TOL * max(1.0, float(ref.abs().max())), (nm, err, float(ref.abs().max()))
+    assert abs(float(eng.loss) - float(loss_r)) <= LOSS_TOL, (float(eng.loss), float(loss_r))
+    assert _rel(eng.center_sum, bsum[0]) < 1e-5
+    got = eng.grads()
+    keys = [k for k, r in grads_r.items() if r is not None and k != "head.last_layer.weight_g"]
+    gn_g = math.sqrt(sum(float((got[k].double() ** 2).sum()) for k in keys))
+    gn_r = math.sqrt(sum(float((grads_r[k].double() ** 2).sum()) for k in keys))
+    assert abs(gn_g - gn_r) <= GNORM_TOL * gn_r, (gn_g, gn_r)
+    worst = max((_rel(got[k], grads_r[k]), k) for k in keys if float(grads_r[k].abs().max()) > 1e-12)
+    assert worst[0] <= GRAD_TOL, f"gradient mismatch {worst}"
+    print(f"[fp32 dino {arch} n_local={n_local}] loss {abs(float(eng.loss) - float(loss_r)):.2e}, grad-norm rel {abs(gn_g - gn_r) / gn_r:.2e}, "
+          f"worst parameter gradient {worst[0]:.2e} ({worst[1]})")
+    eng.t = 0
+    for i in range(3):
+        r = orc.step(tiles)
+        l = eng.step(tiles.to(dev))
+        assert abs(float(l) - r["loss"]) <= 1e-4, (i, float(l), r["loss"])
+    torch.cuda.synchronize()
+    assert _rel(eng.center, orc.center[0]) < 1e-4
+    sd, td = eng.backbone_state_dict(), eng.backbone_state_dict(teacher=True)
+    for k in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "pos_embed", "norm.weight"):
+        assert _rel(sd[k], orc.p[k]) < 1e-4, (k, _rel(sd[k], orc.p[k]))
+        assert _rel(td[k], orc.tp[k]) < 1e-5, k

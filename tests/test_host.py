@@ -61,6 +61,17 @@ def test_bad_arguments_fail_loudly_without_gpu():
         assert _lib.lib.gv_linear(ctypes.byref(d), None) == -4 and b"GV_EPI" in _lib.lib.gv_last_error(), bad
     e = _lib.gv_adamw_ema_args(); e.p = e.grad = e.m = e.v = 256; e.n = 64; e.mode = 4
     assert _lib.lib.gv_adamw_ema(ctypes.byref(e), None) == -4
+    # fp32 operand mode: same structs, its own checks
+    f = _lib.gv_linear_args(); f.A = f.B = f.C = 256; f.M = f.N = f.K = 100; f.lda = f.ldb = f.ldc = 100
+    assert _lib.lib.gv_linear_f32(ctypes.byref(f), None) == -4 and b"c_is_f32" in _lib.lib.gv_last_error()
+    f.c_is_f32 = 1; f.epilogue = 1      # BIAS without a bias
+    assert _lib.lib.gv_linear_f32(ctypes.byref(f), None) == -3
+    g = _lib.gv_attention_fwd_args(256, 256, 256, 2, 300, 3, 0.125)
+    assert _lib.lib.gv_attention_fwd_f32(ctypes.byref(g), None) == -1 and b"260" in _lib.lib.gv_last_error()
+    from gipvit.engine import SupervisedEngine, DinoEngine
+    for cls in (SupervisedEngine, DinoEngine):
+        with pytest.raises(ValueError, match="precision"):
+            cls(precision="fp16", device="cpu")
 
 
 def test_arena_layout_and_decay_split():
@@ -253,7 +264,7 @@ def test_every_used_flag_is_read_by_the_driver():
             assert reads == 0, f"{e['flags']} is read by train.py but marked used=False"
     # values the build cannot honour are refused before any GPU work
     for bad in (["--drop", "0.1"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "agc"], ["--in-chans", "1"],
-                ["--input-size", "3", "224", "200"], ["--dino", "--supervised"]):
+                ["--input-size", "3", "224", "200"], ["--dino", "--supervised"], ["--amp", "--amp-dtype", "bfloat16", "--precision", "fp32"]):
         args, _ = train.parse_args(["--model", "vit_tiny"] + bad)
         with pytest.raises(SystemExit):
             train.check_supported(args, lambda m: None)

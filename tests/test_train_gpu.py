@@ -164,3 +164,22 @@ def test_train_dino_drop_path(dev, tmp_path):
     assert _rel(w["dp_a"], w["plain"]) > 1e-4
     rows = list(csv.DictReader(open(tmp_path / "dp_a" / "summary.csv")))
     assert 5.0 < float(rows[0]["train_loss"]) < 8.0
+
+
+def test_train_precision_fp32(dev, tmp_path):
+    """--precision fp32 through the driver (the reference's arithmetic without --amp): training, the EMA copy and the
+    per-epoch slide validation all run on the f32 kernels; the run stays close to the bf16 run of the same seed (same
+    data, same draws) without being identical to it."""
+    sys.path.insert(0, ROOT)
+    import train
+    common = ["--model", "vit_tiny_patch16_224", "--dataset", "synthetic", "--num-classes", "2", "--img-size", "64", "--tile-size", "64",
+              "-b", "8", "--batches-per-epoch", "4", "--opt", "adamw", "--lr", "1e-4", "--sched", "cosine", "--epochs", "1",
+              "--log-interval", "2", "--output", str(tmp_path), "--seed", "1", "--synthetic-slides", "4", "--num_tiles", "12",
+              "--tiles_per_iter", "5", "--model-ema", "--model-ema-decay", "0.9"]
+    assert train.main(common + ["--experiment", "f32", "--precision", "fp32"]) == 0
+    assert train.main(common + ["--experiment", "b16"]) == 0
+    rows = {n: list(csv.DictReader(open(tmp_path / n / "summary.csv")))[0] for n in ("f32", "b16")}
+    assert abs(float(rows["f32"]["train_loss"]) - float(rows["b16"]["train_loss"])) < 5e-3
+    assert abs(float(rows["f32"]["eval_loss"]) - float(rows["b16"]["eval_loss"])) < 5e-3
+    w = {n: torch.load(tmp_path / n / "last.pth.tar", weights_only=True)["state_dict"]["blocks.11.mlp.fc2.weight"] for n in ("f32", "b16")}
+    assert 0 < _rel(w["f32"], w["b16"]) < 2e-2

@@ -93,6 +93,9 @@ def build_parser():
     g.add_argument("--no-validate", action="store_true", help="skip the per-epoch slide-level validation")
     g.add_argument("--features-dir", default="./TCGA_500", help="where --extract_features writes <slide>_features.pt (train.py:1282)")
     g.add_argument("--device", default="cuda", help="must be a GPU: the hot path has no CPU fallback")
+    g.add_argument("--precision", default="bf16", choices=("bf16", "fp32"), help="bf16: bf16 GEMM / attention operands, f32 accumulation, f32 "
+                   "residual stream and master weights (the training path).  fp32: every operand f32 -- the reference's arithmetic "
+                   "without --amp; a verification mode, an order of magnitude slower")
     return cfg, p
 
 
@@ -133,9 +136,12 @@ def check_supported(args, log=_logger.warning):
     if args.amp and args.amp_dtype not in ("bfloat16", "bf16"):
         log(f"--amp --amp-dtype {args.amp_dtype}: fp16 autocast + loss scaling (train.py:452-465, 585-602) is not built; this build's "
             "GEMMs always take bf16 operands with f32 accumulation and f32 master weights (the --amp-dtype bfloat16 arithmetic)")
-    elif not args.amp:
+    elif not args.amp and args.precision != "fp32":
         log("no --amp: the reference would compute in fp32 (train.py:452-465); this build's GEMMs take bf16 operands with f32 "
-            "accumulation, f32 residual stream and f32 master weights (the --amp --amp-dtype bfloat16 arithmetic)")
+            "accumulation, f32 residual stream and f32 master weights (the --amp --amp-dtype bfloat16 arithmetic) unless "
+            "--precision fp32 is given")
+    if args.amp and args.precision == "fp32":
+        raise SystemExit("--amp asks for mixed precision, --precision fp32 for f32 operands throughout: pick one")
     if args.supervised and args.dino:
         raise SystemExit("--supervised (fine-tune with labels, train.py:715-717) and --dino (self-supervised) exclude each other")
     return img
@@ -255,7 +261,7 @@ def main(argv=None):
         eng = DinoEngine(arch=arch, img_size=img, out_dim=args.out_dim, batch=B, tile=tile, n_local=args.local_crops_number,
                          gsize=args.global_crop_size, lsize=args.local_crop_size, lr=lr, weight_decay=args.weight_decay, betas=betas, eps=eps,
                          momentum_teacher=args.momentum_teacher, teacher_temp=args.teacher_temp, clip_grad=args.clip_grad or 0.0,
-                         mean=mean, std=std, device=dev, reducer=reducer)
+                         mean=mean, std=std, device=dev, reducer=reducer, precision=args.precision)
         bb = (M.load_encoder_checkpoint(args.initial_checkpoint, arch, img) if args.initial_checkpoint
               else M.init_vit_state(arch, img, 0, seed=args.seed))
         eng.load_state(bb, M.init_dino_head_state(eng.D, args.out_dim, seed=args.seed + 1))
@@ -266,7 +272,7 @@ def main(argv=None):
         eng = SupervisedEngine(arch=arch, img_size=img, num_classes=nc, batch=B, lr=lr, weight_decay=args.weight_decay, betas=betas, eps=eps,
                                smoothing=args.smoothing, clip_grad=args.clip_grad or 0.0, mean=mean, std=std, device=dev, reducer=reducer,
                                opt=opt if opt in ("adam", "adamw", "sgd") else "adamw", momentum=args.momentum,
-                               train_backbone=not args.no_grad, model_ema_decay=ema_decay)
+                               train_backbone=not args.no_grad, model_ema_decay=ema_decay, precision=args.precision)
         st = (M.load_encoder_checkpoint(args.initial_checkpoint, arch, img, nc) if args.initial_checkpoint
               else M.init_vit_state(arch, img, nc, seed=args.seed))
         eng.load_state(st)
@@ -299,7 +305,7 @@ def main(argv=None):
     runner = runner_ema = None
     if inf_loader is not None:
         if args.dino:       # features come from the teacher backbone (the model DINO users evaluate)
-            runner = FeatureExtractor(arch, tile, eval_B, 0, mean, std, dev, weights=Weights(eng.arena, "backbone.", teacher=True))
+            runner = FeatureExtractor(arch, tile, eval_B, 0, mean, std, dev, weights=Weights(eng.arena, "backbone.", teacher=True, fp32=args.precision == "fp32"))
             if tile != img:
                 raise SystemExit(f"--extract_features with --dino: tile size {tile} must equal the teacher's image size {img}")
         else:
