@@ -267,3 +267,64 @@ def test_fp32_dino_step_gates(dev, arch, n_local, K):
     for k in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "pos_embed", "norm.weight"):
         assert _rel(sd[k], orc.p[k]) < 1e-4, (k, _rel(sd[k], orc.p[k]))
         assert _rel(td[k], orc.tp[k]) < 1e-5, k
+
+
+@gpu
+@pytest.mark.parametrize("arch,D,steps", [("vit_small", 384, 10), ("vit_base", 768, 0)])
+def test_headline_config_bf16_step_against_fp32_mode(dev, arch, D, steps):
+    """BASELINE config 3 at its FULL size (ViT-S/16, 64 tiles of 256 px, 2 x 224 + 8 x 96 crops, K = 65536, stochastic
+    depth 0.1) -- a size the CPU oracle cannot reach in test time.  The fp32 operand mode, pinned to the oracle at the
+    fp32 gates by the tests above, is the reference here: the bf16 training path (full-row fused kernels, grouped dW, 251
+    workgroups per launch -- none of which the small-shape tests reach at this row count) must agree with it at the bf16
+    gates: logits 2e-2 of the largest, loss 1e-3, per-parameter gradient 5e-2, gradient norm 1e-2; ten optimizer steps stay
+    within 1e-3 of the fp32 loss curve.  The ViT-B case is config 5's per-micro-batch shape (64 tiles; the 128 x 128-tile
+    GEMMs and the stand-alone LayerNorm kernels at 44 160 token rows)."""
+    from gipvit.engine import DinoEngine
+    from gipvit.models import init_vit_state, init_dino_head_state
+    from oracle import vit_oracle as vo
+    B, K = 64, 65536
+    mk = lambda prec: DinoEngine(arch=arch, img_size=224, out_dim=K, batch=B, n_local=8, lr=5e-4 * B / 256, weight_decay=0.04,
+                                 clip_grad=3.0, device=dev, precision=prec)
+    bb, hd = init_vit_state(arch, 224, 0, seed=0), init_dino_head_state(D, K, seed=1)
+    tiles = vo.synth_tiles(B, 256, seed=99).to(dev)
+    drop = vo.drop_path_factors(12, 10 * B, 0.1, torch.Generator().manual_seed(4)).to(dev)
+    c = (0.05 * torch.randn(K, generator=torch.Generator().manual_seed(3))).to(dev)
+    out = {}
+    for prec in ("fp32", "bf16"):
+        eng = mk(prec)
+        eng.load_state(bb, hd)
+        eng.center.copy_(c)
+        eng.set_drop_path(drop)
+        eng.set_hyper()
+        eng.forward_backward(tiles)
+        torch.cuda.synchronize()
+        out[prec] = dict(loss=float(eng.loss), s=eng.hb_s.logits.float().cpu(), t=eng.hb_t.logits.float().cpu(),
+                         cs=eng.center_sum.cpu(), g={k: v.cpu() for k, v in eng.grads().items()})
+        # ... then ten full steps (optimizer, teacher EMA, centre, gradient clipping) at a warm-up learning rate
+        eng.t = 0
+        out[prec]["curve"] = [float(eng.step(tiles, lr=1e-5)) for _ in range(steps)]
+        out[prec]["w"] = eng.backbone_state_dict()["blocks.11.mlp.fc2.weight"].cpu()
+        del eng
+        torch.cuda.empty_cache()
+    r, b = out["fp32"], out["bf16"]
+    assert math.isfinite(r["loss"]) and 10.0 < r["loss"] < 12.0          # ln(65536) = 11.09 at initialisation
+    for nm in ("s", "t"):
+        err, top = float((b[nm] - r[nm]).abs().max()), float(r[nm].abs().max())
+        assert err <= 2e-2 * top, (nm, err, top)
+    assert abs(b["loss"] - r["loss"]) <= 1e-3, (b["loss"], r["loss"])
+    assert _rel(b["cs"], r["cs"]) < 1e-2
+    keys = [k for k in r["g"] if k != "head.last_layer.weight_g" and float(r["g"][k].abs().max()) > 1e-12]
+    worst = max((_rel(b["g"][k], r["g"][k]), k) for k in keys)
+    gn_b = math.sqrt(sum(float((b["g"][k].double() ** 2).sum()) for k in keys))
+    gn_r = math.sqrt(sum(float((r["g"][k].double() ** 2).sum()) for k in keys))
+    print(f"[{arch}, full size] loss bf16 {b['loss']:.5f} vs fp32 {r['loss']:.5f}, worst parameter gradient {worst[0]:.2e} ({worst[1]}), "
+          f"grad-norm rel {abs(gn_b - gn_r) / gn_r:.2e}")
+    assert worst[0] <= 5e-2, worst
+    assert abs(gn_b - gn_r) <= 1e-2 * gn_r, (gn_b, gn_r)
+    if not steps:
+        return
+    dcurve = max(abs(x - y) for x, y in zip(b["curve"], r["curve"]))
+    print(f"[{arch}, full size] {steps} steps: max |dloss| {dcurve:.2e}, final {b['curve'][-1]:.5f} vs {r['curve'][-1]:.5f}, "
+          f"weights rel {_rel(b['w'], r['w']):.2e}")
+    assert dcurve <= 1e-3, (b["curve"], r["curve"])
+    assert _rel(b["w"], r["w"]) < 1e-3
