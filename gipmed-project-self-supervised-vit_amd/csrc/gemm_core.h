@@ -76,14 +76,20 @@ __device__ __forceinline__ void glds16(const void* src, GV_LDS char* dst) {
 // partner is inside an MFMA cluster at raised priority: every VALU instruction of the load segment waits for a free issue slot)
 // (the instruction's immediate offset is added to the LDS address as well as to the global one, as for MUBUF LDS loads:
 // M0 is set IMM short of the destination)
-template <int IMM>
+template <int IMM, bool NT = false>      // NT: nontemporal hint for operands this step never reads again
 __device__ __forceinline__ void glds16_s(unsigned long long sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     lds_dst -= IMM;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
-                 : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
+                     : "memory");
 }
 
 // Per-lane source pointers of one operand tile (one per LDS-DMA piece this wave issues), set

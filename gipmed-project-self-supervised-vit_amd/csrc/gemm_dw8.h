@@ -96,7 +96,11 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
         constexpr int X = decltype(Xc)::value, STG = decltype(Sc)::value, img = X >> 1, pc = X & 1;
         const unsigned dst = lds0 + STG * DW8_STAGE + img * DW8_IMG + pc * 1024;
         if constexpr (img == 0) glds16_s<0>(baseP + (unsigned long long)u * stepP, voffP[pc], dst);
+#ifdef GV_NT_DWX    // lab: the 384-wide operand is the saved forward activation (h, xn2, o, xn1): last use in the step
+        else glds16_s<(img - 1) * 256, true>(baseQ + (unsigned long long)u * stepQ, voffQ[pc], dst);
+#else
         else glds16_s<(img - 1) * 256>(baseQ + (unsigned long long)u * stepQ, voffQ[pc], dst);
+#endif
     };
     // ragged last K-tile of the slice / the dummy tiles behind it: rows past the slice read zeros
     auto issue_slow = [&](auto Xc, auto Sc, int u) {
