@@ -159,20 +159,28 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     };
     // ---- PP: pieces of a K-tile in DMA-stream order: A (a = A_PPW per wave), W0, W1, W2 (two per wave each); n = a + 6
     constexpr int PA = C::A_PPW, PN_T = PA + 6;
-    auto issue_x = [&](auto Xc, int u) {
+    // Tile nt (the one the stream reaches behind a block's last): MODE_WIDE with another column block to come -- that block's
+    // tile 0 (same A rows from k = 0, the next 384 weight rows), so the stream runs on across the block boundary; otherwise a
+    // re-read of the last tile that is never consumed (keeps the counted waits uniform).  Tile nt + 1 is never issued: the
+    // last tile's phases run the TAIL variant below.
+    // A phase resolves "past the end" once, with scalar selects, for the pieces it issues: (uc, bw) = the tile's k index and
+    // weight base, uc_past / bw_past (set per block) for tile nt.
+    const unsigned long long wstep = (unsigned long long)(TB ? (long)PN * 2 : (long)PN * p.ldw * 2);    // bytes from one column block's weights to the next
+    int uc_past = nt - 1;
+    unsigned long long bw_past = baseW;
+    auto issue_x = [&](auto Xc, int u, int uc, unsigned long long bw) {
         constexpr int X = decltype(Xc)::value;
-        const int uc = u < nt ? u : nt - 1;                   // tiles past the end re-read the last one: never consumed, keeps the counted waits uniform
         const unsigned st = lds0 + (u & 1) * C::STAGE;
         if constexpr (X < PA) {
             glds16_s<0>(baseA + (unsigned long long)uc * (BK * 2), voffA[X], st + (wave * PA + X) * 1024);
         } else {
             constexpr int b = (X - PA) / 2, pc = (X - PA) % 2;
             const unsigned dst = st + C::A_BYTES + b * C::W_BLOCK + (wave * 2 + pc) * 1024;
-            if constexpr (!TB) glds16_s<0>(baseW + ((unsigned long long)(128 * b) * p.ldw + (unsigned long long)uc * BK) * 2, voffW[pc], dst);
-            else glds16_s<b * 256>(baseW + (unsigned long long)uc * BK * p.ldw * 2, voffW[pc], dst);
+            if constexpr (!TB) glds16_s<0>(bw + ((unsigned long long)(128 * b) * p.ldw + (unsigned long long)uc * BK) * 2, voffW[pc], dst);
+            else glds16_s<b * 256>(bw + (unsigned long long)uc * BK * p.ldw * 2, voffW[pc], dst);
         }
     };
-    if constexpr (PP) static_for<0, PN_T>([&](auto X) { issue_x(X, 0); }); else
+    if constexpr (PP) static_for<0, PN_T>([&](auto X) { issue_x(X, 0, 0, baseW); }); else
     issue(0);
     // MODE_WIDE walks the 384-column blocks of the output with the same row panel: the A rows are staged again per block (from
     // L2), the block's first ring stage is requested before the previous block's epilogue (whose image lives in stage 1 and
@@ -185,6 +193,9 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         for (int e = 0; e < 2; ++e) { s_dg[c][e] = 0.f; s_db[c][e] = 0.f; s_g[c][e] = 0.f; }
     for (int cb = 0; cb < ncb; ++cb) {
     if constexpr (PP) {
+        const bool has_next = MODE == MODE_WIDE && cb + 1 < ncb;
+        uc_past = has_next ? 0 : nt - 1;
+        bw_past = has_next ? baseW + wstep : baseW;
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc8[b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // prologue: tile 0 is out (start of the kernel / before the previous block's epilogue); A, W0, W1 of tile 1 follow
-        static_for<0, PA + 4>([&](auto X) { issue_x(X, 1); });
+        static_for<0, PA + 4>([&](auto X) { issue_x(X, 1, 1, baseW); });
         wait_vmcnt<PN_T + 2>();                               // A and W0 of tile 0 landed
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -209,8 +220,11 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         //   (t, 0) retires W1(t): n + 2 pieces may fly; (t, 1) retires W2(t): n + a; (t, 2) retires A, W0 of t + 1: n + 2.
         // WAR: the reads of a load segment are retired (lgkmcnt(0)) before its barrier, the image is restaged one phase
         // later at the earliest (A: read (t, 0), restaged (t, 1); W0: (t, 0) / (t, 2); W1: (t, 1) / (t, 2); W2: (t, 2) / (t + 1, 0)).
+        // The block's last tile (t = nt - 1, always in stage 1): its W2 pieces are tile nt's, nothing of tile nt + 1 is issued,
+        // and what may still fly when W2(t) / A, W0 of tile nt must have landed is then n / 4 pieces (uniform branches).
         auto phase = [&](auto Jc, auto Sc, int t) {
             constexpr int J = decltype(Jc)::value, S = decltype(Sc)::value;
+            const bool tail = S == 1 && t == nt - 1;
             GV_LDS char* st = smem + S * C::STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -221,9 +235,22 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int i = 0; i < FMH; ++i) fa[ks][i] = read_frag<false, C::A_ROWS, BK>(st, f0 + i, ks, lane);
-                static_for<PA + 4, PN_T>([&](auto X) { issue_x(X, t + 1); }); wait_vmcnt<PN_T + 2>();
-            } else if constexpr (J == 1) { static_for<0, PA>([&](auto X) { issue_x(X, t + 2); }); wait_vmcnt<PN_T + PA>(); }
-            else { static_for<PA, PA + 4>([&](auto X) { issue_x(X, t + 2); }); wait_vmcnt<PN_T + 2>(); }
+                const bool past = t + 1 >= nt;
+                const int uc = past ? uc_past : t + 1;
+                const unsigned long long bw = past ? bw_past : baseW;
+                static_for<PA + 4, PN_T>([&](auto X) { issue_x(X, t + 1, uc, bw); }); wait_vmcnt<PN_T + 2>();
+            } else {
+                const bool past = t + 2 >= nt;
+                const int uc = past ? uc_past : t + 2;
+                const unsigned long long bw = past ? bw_past : baseW;
+                if constexpr (J == 1) {
+                    if (tail) wait_vmcnt<PN_T>();
+                    else { static_for<0, PA>([&](auto X) { issue_x(X, t + 2, uc, bw); }); wait_vmcnt<PN_T + PA>(); }
+                } else {
+                    if (tail) wait_vmcnt<4>();
+                    else { static_for<PA, PA + 4>([&](auto X) { issue_x(X, t + 2, uc, bw); }); wait_vmcnt<PN_T + 2>(); }
+                }
+            }
             __builtin_amdgcn_s_waitcnt(0xC07F);               // this segment's reads are retired before its barrier
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -305,10 +332,8 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         if (cb + 1 < ncb) {                   // next block's weights; its first stage goes out now (stage 0 was last read at step nt - 2)
 #pragma unroll
             for (int j = 0; j < 3; ++j) if constexpr (!PP) srcW[j].setup(p.W, p.ldw, (cb + 1) * PN + 128 * j, n_total, wave, lane);
-            if constexpr (PP) {
-                baseW = (unsigned long long)(TB ? p.W + (long)(cb + 1) * PN : p.W + (long)(cb + 1) * PN * p.ldw);
-                static_for<0, PN_T>([&](auto X) { issue_x(X, 0); });
-            } else
+            if constexpr (PP) baseW += wstep;     // (its tile 0 went out as tile nt of this block's stream)
+            else
             issue(0);
         }
     }
