@@ -452,7 +452,12 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                             }
                             if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v[c][0] = gelu_f(v[c][0]); v[c][1] = gelu_f(v[c][1]); }
                             if constexpr (EP == EP_DGELU) { v[c][0] *= dgelu_f((float)pre_x[rr][c][0]); v[c][1] *= dgelu_f((float)pre_x[rr][c][1]); }
-                            *(bf16x2*)(orow + col) = bf16x2{(bf16)v[c][0], (bf16)v[c][1]};
+                            // The output streams through the 4-MB L2 of the XCD and evicts what the workgroups re-read: their A
+                            // panels (32 per XCD x 16 FM rows x 768 B, fetched once per column block).  Up to FM = 8 the panels
+                            // fit L2 beside the weights -- if the output is stored nontemporally (the teacher's fc1 / qkv, FM = 7:
+                            // 63 -> 54 us, 46 -> 39 us); at FM = 11 they do not fit anyway and the hint costs 1 - 2 us.
+                            if constexpr (FM <= 8) __builtin_nontemporal_store(bf16x2{(bf16)v[c][0], (bf16)v[c][1]}, (bf16x2*)(orow + col));
+                            else *(bf16x2*)(orow + col) = bf16x2{(bf16)v[c][0], (bf16)v[c][1]};
                         }
                     } else if constexpr (MODE == MODE_FWD) {
                         float* orow = p.out + (long)m * p.ldo;
@@ -477,9 +482,14 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                             const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * (1.0f / PN) + p.eps);
                             bf16* yrow = p.y + (long)m * PN;
 #pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                *(bf16x2*)(yrow + (c * 64 + lane) * 2) = bf16x2{(bf16)((v[c][0] - mean) * rstd * gm[c][0] + bt[c][0]),
-                                                                                (bf16)((v[c][1] - mean) * rstd * gm[c][1] + bt[c][1])};
+                            for (int c = 0; c < 3; ++c) {
+                                const bf16x2 yv = bf16x2{(bf16)((v[c][0] - mean) * rstd * gm[c][0] + bt[c][0]), (bf16)((v[c][1] - mean) * rstd * gm[c][1] + bt[c][1])};
+#ifdef GV_NT_Y
+                                __builtin_nontemporal_store(yv, (bf16x2*)(yrow + (c * 64 + lane) * 2));
+#else
+                                *(bf16x2*)(yrow + (c * 64 + lane) * 2) = yv;
+#endif
+                            }
                             if (lane == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
                         }
                     } else {
@@ -513,12 +523,10 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                                 gbv[e] = gv[c][e] * gs;
                                 s_g[c][e] += gbv[e];
                             }
-#ifdef GV_NT_G        // lab: same for the f32 residual gradient
+                            // nontemporal: neither row is read again by this launch, and 100 MB of them would pass through the L2
+                            // that holds the weights every workgroup re-reads (fc1-dX + LayerNorm backward 88.3 -> 85.7 us)
                             __builtin_nontemporal_store(f32x2{gv[c][0], gv[c][1]}, (f32x2*)(grow + col));
-#else
-                            *(f32x2*)(grow + col) = f32x2{gv[c][0], gv[c][1]};
-#endif
-                            if (p.gb) *(bf16x2*)(p.gb + (long)m * p.ldgb + col) = bf16x2{(bf16)gbv[0], (bf16)gbv[1]};
+                            if (p.gb) __builtin_nontemporal_store(bf16x2{(bf16)gbv[0], (bf16)gbv[1]}, (bf16x2*)(p.gb + (long)m * p.ldgb + col));
                         }
                     }
                 }

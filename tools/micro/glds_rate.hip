@@ -86,8 +86,11 @@ __global__ __launch_bounds__(512, 1) void fill_mix(const char* src, int iters) {
     const char* l2 = src;
     long ph = (long)wave * 1024, pl = (long)wave * 1024;
     for (int i = 0; i < iters; ++i) {
-        const bool from_hbm = MIX == 0 || (MIX == 1 && i % 3 == 0);
-        const char* p = from_hbm ? hbm + (ph & ((4L << 20) - 1)) : l2 + (pl & ((1L << 20) - 1));
+        const bool from_hbm = MIX == 0 || MIX == 3 || ((MIX == 1 || MIX == 4) && i % 3 == 0);
+        // MIX 3 / 4: the "HBM" window is 512 KB per CU (128 MB over the chip: past the 8 x 4 MB of L2, inside the 256-MB Infinity
+        // Cache) and is walked many times -- Infinity-Cache hits after the first pass
+        const long hwin = (MIX >= 3 ? (512L << 10) : (4L << 20)) - 1;
+        const char* p = from_hbm ? hbm + (ph & hwin) : l2 + (pl & ((1L << 20) - 1));
         if (from_hbm) ph += 8 * 1024; else pl += 8 * 1024;
         glds16(p + lane * 16, lds0 + (i & 15) * 1024);
 #pragma unroll
@@ -154,7 +157,7 @@ int main(int argc, char** argv) {
     auto runm = [&](const char* name, auto kern, int inflight, int mix) {
         if (only >= 0 && only != idx++) return;
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        const int iters = mix == 0 ? 1024 : 3072;       // (a pure-HBM wave walks its 4 MB window at most twice: no MALL re-use)
+        const int iters = mix == 0 ? 1024 : (mix >= 3 ? 6144 : 3072);       // (a pure-HBM wave walks its 4 MB window at most twice: no MALL re-use)
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             hipLaunchKernelGGL(kern, dim3(256), dim3(512), 131072, 0, buf, iters);
@@ -168,6 +171,11 @@ int main(int argc, char** argv) {
     };
 #define RUNM(I) runm("one WG per CU, all HBM", fill_mix<I, 0>, I, 0); runm("one WG per CU, 1/3 HBM + 2/3 L2", fill_mix<I, 1>, I, 1); runm("one WG per CU, all L2", fill_mix<I, 2>, I, 2);
     RUNM(1) RUNM(2) RUNM(4) RUNM(8) RUNM(12) RUNM(16)
+    runm("one WG per CU, all Infinity Cache", fill_mix<1, 3>, 1, 3); runm("one WG per CU, all Infinity Cache", fill_mix<2, 3>, 2, 3);
+    runm("one WG per CU, all Infinity Cache", fill_mix<4, 3>, 4, 3); runm("one WG per CU, all Infinity Cache", fill_mix<8, 3>, 8, 3);
+    runm("one WG per CU, all Infinity Cache", fill_mix<16, 3>, 16, 3);
+    runm("one WG per CU, 1/3 Inf. Cache + 2/3 L2", fill_mix<4, 4>, 4, 4); runm("one WG per CU, 1/3 Inf. Cache + 2/3 L2", fill_mix<8, 4>, 8, 4);
+    runm("... 1/3 Inf. Cache + 2/3 L2, 3 ds_read_b128 per piece", fill_mix<8, 4, 3>, 8, 4);
     runm("... 1/3 HBM + 2/3 L2, 3 ds_read_b128 per piece", fill_mix<8, 1, 3>, 8, 1);
     runm("... 1/3 HBM + 2/3 L2, 6 ds_read_b128 per piece", fill_mix<8, 1, 6>, 8, 1);
     runm("... all L2, 3 ds_read_b128 per piece", fill_mix<8, 2, 3>, 8, 2);

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Lab: which operands should carry a nontemporal hint so that the NEXT kernel's A operand is still in L2 / Infinity Cache?
-# The product stores the saved GELU pre-activation nontemporally (fc1's epilogue); this script times further candidates
-# against it on one box, back to back: -DGV_NT_DWX (the saved activations the dW launch reads), -DGV_NT_X (LayerNorm
-# backward's input row), -DGV_NT_AUX_LD (the pre-activation read of GELU'-dX), -DGV_NT_XOUT / -DGV_NT_G (the f32 residual row /
-# residual gradient row stores of the full-row kernels).  Prints the per-kernel rows of every build.
+# The product stores nontemporally: the saved GELU pre-activation (fc1's epilogue), the wide products' outputs up to FM = 8,
+# the residual-gradient rows of the backward full-row kernel.  This script times further candidates against it on one box,
+# back to back: -DGV_NT_XOUT / -DGV_NT_Y (the f32 residual row / the LayerNorm output of the forward full-row kernel),
+# -DGV_NT_X (LayerNorm backward's input row), -DGV_NT_AUX_LD (the pre-activation read of GELU'-dX), -DGV_NT_DWX (the saved
+# activations the dW launch stages: slower, its workgroups share them through L2).  Prints the per-kernel rows of every build.
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 PKG="$ROOT/gipmed-project-self-supervised-vit_amd"
@@ -20,7 +21,7 @@ python3 "$ROOT/bench.py" --no-cpu-baseline > "$ROOT/gpurun_out/nt_base.json" 2> 
 show "$ROOT/gpurun_out/nt_base.json"
 cp "$PKG/libgipvit_hip.so" /tmp/libgipvit_product.so
 i=0
-for DEFS in "-DGV_NT_DWX" "-DGV_NT_XOUT" "-DGV_NT_G" "-DGV_NT_XOUT -DGV_NT_G -DGV_NT_DWX -DGV_NT_X -DGV_NT_AUX_LD"; do
+for DEFS in "-DGV_NT_XOUT" "-DGV_NT_Y" "-DGV_NT_X -DGV_NT_AUX_LD"; do
     i=$((i+1))
     "$HIPCC" --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $DEFS -c "$PKG/csrc/panel.hip" -o /tmp/panel_lab.o
     "$HIPCC" --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $DEFS -c "$PKG/csrc/gemm.hip" -o /tmp/gemm_lab.o
