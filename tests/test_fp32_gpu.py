@@ -328,3 +328,27 @@ def test_headline_config_bf16_step_against_fp32_mode(dev, arch, D, steps):
           f"weights rel {_rel(b['w'], r['w']):.2e}")
     assert dcurve <= 1e-3, (b["curve"], r["curve"])
     assert _rel(b["w"], r["w"]) < 1e-3
+
+
+@gpu
+def test_fp32_feature_extractor_and_model_seam(dev):
+    """The forward-only encoder (slide validation / --extract_features) and the create_model seam in the fp32 operand mode:
+    CLS features and logits against the oracle's forward at 1e-5 relative (2e-2 / 3e-2 in bf16), with any number of tiles
+    through the padded last batch."""
+    from gipvit.engine import FeatureExtractor
+    from gipvit import models
+    from oracle import vit_oracle as vo
+    p = vo.init_vit("vit_small", 64, 2, seed=4)
+    fx = FeatureExtractor(arch="vit_small", img_size=64, batch=6, num_classes=2, device=dev, precision="fp32")
+    assert fx.feats.dtype == f32
+    fx.load_state(p)
+    tiles = vo.synth_tiles(10, 64, seed=21)
+    feats, logits = fx.run(tiles.to(dev))                       # 6 + 4 (padded)
+    torch.cuda.synchronize()
+    x = vo.normalize_window(tiles, (0, 0, 64))
+    ref_f, ref_l = vo.vit_features(p, x, "vit_small"), vo.vit_logits(p, x, "vit_small")
+    assert _rel(feats, ref_f) < 1e-5 and _rel(logits, ref_l) < 1e-5, (_rel(feats, ref_f), _rel(logits, ref_l))
+    m = models.create_model("vit_small_patch16_224", num_classes=2, img_size=64, batch=10, device=dev, precision="fp32")
+    m.load_state_dict(p)
+    out = m(tiles.to(dev))
+    assert out.dtype == f32 and _rel(out, ref_l) < 1e-5
