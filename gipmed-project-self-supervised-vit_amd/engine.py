@@ -672,6 +672,8 @@ class DinoEngine:
         self.t = 0
         self.reducer = reducer if reducer is not None else NoReducer()
         self._n_micro = 1
+        # the teacher's forward runs on the side stream beside the student's; GIPVIT_TEACHER_SIDE=0 queues it in front instead (A/B runs)
+        self._teacher_on_side = os.environ.get("GIPVIT_TEACHER_SIDE", "1") != "0"
         if torch.device(device).type == "cuda":
             self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         # contiguous arena range of every block's weight-decayed matrices (arena order = backward order)
@@ -771,7 +773,8 @@ class DinoEngine:
         # the teacher's forward shares nothing with the student's until the loss: it runs on the
         # side stream beside the student forward (fills the tail of each other's kernels)
         side = self.vit.side if tiles_u8.is_cuda else None
-        if side is not None:
+        t_side = side if self._teacher_on_side else None
+        if t_side is not None:
             main = torch.cuda.current_stream()
             self._ev_fork.record(main); side.wait_event(self._ev_fork)
             with torch.cuda.stream(side):
@@ -783,7 +786,7 @@ class DinoEngine:
             self.head.forward(self.tH, self.wn_t, self.hb_t)
         self.vit.forward(self.sW, self.g_stu, s_src, s_win, self.mean, self.std, self.hb_s.feats, fill=fill)
         self.head.forward(self.sH, self.wn_s, self.hb_s)
-        if side is not None:
+        if t_side is not None:
             main.wait_event(self._ev_join)
         ops.dino_loss(self.hb_s.logits, self.hb_t.logits, self.center, self.hb_s.dlogits, self.loss, self.center_sum,
                       self.loss_ws, B, V, G, self.K, self.ts, self.tt, hyper=self.hyper)
