@@ -90,7 +90,9 @@ struct PanelP {
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_WIDE = 2 };
 // MODE_WIDE epilogues (the GV_EPI_* combinations of the hot path's wide products)
-enum { EP_NONE = 0, EP_BIAS = 1, EP_BIAS_GELU = 2, EP_BIAS_GELU_SAVE = 3, EP_DGELU = 4 };
+// EP_BIAS_RESID: f32 output = (A W^T + bias) * row_scale + resid -- x + proj(a) / x + fc2(h) of the widths that have no fused
+// LayerNorm kernel (ViT-B: N = 768)
+enum { EP_NONE = 0, EP_BIAS = 1, EP_BIAS_GELU = 2, EP_BIAS_GELU_SAVE = 3, EP_DGELU = 4, EP_BIAS_RESID = 5 };
 
 // PP = 1: the k-loop of gemm_dw8.h (ping-pong halves, three phases per 64-deep K-tile, counted LDS-DMA stream) instead of the
 // one-stage-ahead loop: waves (wm, wn) = (wave >> 2, wave & 3); the wm = 0 half owns the first FMH = ceil(FM / 2) row fragments,
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     static_assert(!PP || IB * 16 * IMG_STRIDE * 4 + (MODE == MODE_WIDE ? C::STAGE : 0) <= (MODE == MODE_WIDE ? C::LDS_WIDE : C::LDS), "PP image");
     constexpr int RPW = 16 * IB / NW;                             // rows per wave and pass
     GV_LDS float* img = (GV_LDS float*)(smem + (MODE == MODE_WIDE ? C::STAGE : 0));
-    constexpr bool HAS_BIAS = MODE == MODE_FWD || (MODE == MODE_WIDE && EP >= EP_BIAS && EP <= EP_BIAS_GELU_SAVE);
+    constexpr bool HAS_BIAS = MODE == MODE_FWD || (MODE == MODE_WIDE && ((EP >= EP_BIAS && EP <= EP_BIAS_GELU_SAVE) || EP == EP_BIAS_RESID));
     f32x4 bias4[NF], bias8[3][2];
     if constexpr (HAS_BIAS) {
 #pragma unroll
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     for (int i0 = 0; i0 < (PP ? FMH : FM); i0 += (PP ? IBH : IB)) {
         const int ni = PP ? ((FMH - i0) < IBH ? (FMH - i0) : IBH) : ((FM - i0) < IB ? (FM - i0) : IB);          // compile-time after unrolling
         // ---- this wave's global rows of the pass (clamped at M: surplus rows load valid memory and are never stored)
-        f32x2 pre_a[MODE == MODE_WIDE ? 1 : RPW][3], pre_b[MODE == MODE_BWD ? RPW : 1][3];
+        f32x2 pre_a[MODE == MODE_WIDE && EP != EP_BIAS_RESID ? 1 : RPW][3], pre_b[MODE == MODE_BWD ? RPW : 1][3];
         float pre_mean[MODE == MODE_BWD ? RPW : 1], pre_rstd[MODE == MODE_BWD ? RPW : 1];
         bf16x2 pre_x[MODE == MODE_WIDE && EP == EP_DGELU ? RPW : 1][3];
 #pragma unroll
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                 for (int c = 0; c < 3; ++c) {
                     const int col = (c * 64 + lane) * 2;
                     if constexpr (MODE == MODE_WIDE) {
+                        if constexpr (EP == EP_BIAS_RESID) pre_a[rr][c] = *(const f32x2*)(p.resid + (long)m * p.ldr + cb * PN + col);
 #ifdef GV_NT_AUX_LD
                         if constexpr (EP == EP_DGELU) pre_x[rr][c] = __builtin_nontemporal_load((const bf16x2*)(p.aux_in + (long)m * p.ld_aux + cb * PN + col));
 #else
@@ -439,7 +442,13 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                         const f32x2 t2 = *(GV_LDS f32x2*)(img + r * IMG_STRIDE + (c * 64 + lane) * 2);
                         v[c][0] = t2[0]; v[c][1] = t2[1];
                     }
-                    if constexpr (MODE == MODE_WIDE) {
+                    if constexpr (MODE == MODE_WIDE && EP == EP_BIAS_RESID) {
+                        float* orow = p.out + (long)m * p.ldo + cb * PN;
+                        const float rs = p.row_scale ? p.row_scale[m] : 1.0f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            *(f32x2*)(orow + (c * 64 + lane) * 2) = f32x2{fmaf(v[c][0], rs, pre_a[rr][c][0]), fmaf(v[c][1], rs, pre_a[rr][c][1])};
+                    } else if constexpr (MODE == MODE_WIDE) {
                         bf16* orow = p.outb + (long)m * p.ldob + cb * PN;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
@@ -587,7 +596,7 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
     // backward  dY row + f32 x row + f32 g in / out + bf16 g out; + the weight once
     // wide: A row + the bf16 output row (+ the saved / re-read pre-activation row)
     const int nout = MODE == MODE_WIDE ? p.n_total : PN;
-    const double row_bytes = MODE == MODE_WIDE ? 2.0 * p.K + 2.0 * nout * ((EP == EP_BIAS_GELU_SAVE || EP == EP_DGELU) ? 2 : 1)
+    const double row_bytes = MODE == MODE_WIDE ? 2.0 * p.K + (EP == EP_BIAS_RESID ? 8.0 * nout : 2.0 * nout * ((EP == EP_BIAS_GELU_SAVE || EP == EP_DGELU) ? 2 : 1))
                              : MODE == MODE_FWD ? 2.0 * p.K + PN * 4 * 2 + PN * 2 + 8 : 2.0 * p.K + PN * 4 * 3 + PN * 2 + 8;
     const int th = gvtime::enabled() ? gvtime::begin(kname, 2.0 * p.M * nout * p.K, p.M * row_bytes + 2.0 * nout * p.K, s) : -1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS_BYTES, s, p);
@@ -623,8 +632,16 @@ int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
 // the hot path's epilogues, on the full-row kernel -- row panels sized for ONE round of workgroups, 768-B row segments out.
 // Returns -1 when the call is not one of these (the caller then runs the 128x128-tile kernel).
 int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
-    if (a->trans_a || a->c_is_f32 || a->N % PN != 0 || a->K % 128 != 0 || a->M < 2048 || a->ldc % 2 != 0) return -1;
+    if (a->trans_a || a->N % PN != 0 || a->K % 128 != 0 || a->M < 2048 || a->ldc % 2 != 0) return -1;
     if (a->alpha != 0.f && a->alpha != 1.f) return -1;
+    if (a->c_is_f32) {      // x + Linear(a) with an f32 residual stream, where no fused LayerNorm kernel exists for the width
+        if (a->trans_b || a->epilogue != (GV_EPI_BIAS | GV_EPI_RESID) || a->ldr % 2 != 0) return -1;
+        PanelP q{};
+        q.A = (const bf16*)a->A; q.W = (const bf16*)a->B; q.M = a->M; q.K = a->K; q.lda = a->lda; q.ldw = a->ldb;
+        q.bias = a->bias; q.out = (float*)a->C; q.ldo = a->ldc; q.resid = a->resid; q.ldr = a->ldr; q.row_scale = a->row_scale;
+        q.ncb = a->N / PN; q.n_total = a->N;
+        return dispatch_fm<false, MODE_WIDE, EP_BIAS_RESID>(q, s, "gv_linear(wide)");
+    }
     PanelP p{};
     p.A = (const bf16*)a->A; p.W = (const bf16*)a->B; p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldb;
     p.bias = a->bias; p.outb = (bf16*)a->C; p.ldob = a->ldc; p.aux_in = (const bf16*)a->aux_in; p.aux_out = (bf16*)a->aux_out; p.ld_aux = a->ld_aux;

@@ -147,6 +147,21 @@ def test_linear_wide_panel(dev, M, N, K):
     Cs = torch.empty(1000, N, dtype=bf16, device=dev)
     o.linear(Af, Bft, Cs, 1000, N, K, trans_b=True, epilogue=l.EPI_DGELU, aux_in=aux)
     assert torch.equal(Cs, C[:1000])
+    # f32 output with bias + residual (x + proj(a) / x + fc2(h) of the widths without a fused LayerNorm kernel): exact on
+    # integers, one guard row, the same bits as the tile kernel; with stochastic-depth row factors against fp32 torch
+    resid_i = (torch.arange(M * N, device=dev) % 7 - 3).to(f32).view(M, N)
+    Cf = torch.full((M + 1, N), 9.0, dtype=f32, device=dev)
+    o.linear(A, B, Cf, M, N, K, epilogue=l.EPI_BIAS | l.EPI_RESID, bias=bias_i, resid=resid_i)
+    assert torch.equal(Cf[:M], ref + bias_i + resid_i) and float(Cf[M].min()) == 9.0
+    resid = torch.randn(M, N, generator=g).to(dev)
+    rs = (torch.rand(M, generator=g) * 2).to(dev)
+    o.linear(Af, Bf, Cf, M, N, K, epilogue=l.EPI_BIAS | l.EPI_RESID, bias=bias, resid=resid)
+    close(Cf[:M], reff + resid, 1e-4, 1e-4, "bias + resid")
+    Cfs = torch.empty(1000, N, dtype=f32, device=dev)
+    o.linear(Af, Bf, Cfs, 1000, N, K, epilogue=l.EPI_BIAS | l.EPI_RESID, bias=bias, resid=resid)
+    assert torch.equal(Cfs, Cf[:1000])
+    o.linear(Af, Bf, Cf, M, N, K, epilogue=l.EPI_BIAS | l.EPI_RESID, bias=bias, resid=resid, row_scale=rs)
+    close(Cf[:M], reff * rs[:, None] + resid, 1e-4, 1e-4, "row_scale")
 
 
 def test_linear_pos_epilogue(dev):
