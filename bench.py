@@ -201,6 +201,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     loss = float(eng.loss)
+    # roofline of the dominant kernel: a few more steps of the same workload with per-launch timing on -- run by EVERY rank (the
+    # steps contain the data-parallel all-reduces), reported from rank 0
+    roof = roofline.dominant_kernel_roofline(lambda: on_main(lambda: eng.step(tiles)), steps=3, vit=eng.vit)
 
     if rank == 0:
         tiles_s = args.batch * args.micro * world * args.steps / dt
@@ -217,7 +220,7 @@ def main():
             if (args.arch, args.config) in GFLOP_PER_TILE else None,
             "final_loss": round(loss, 4),
         }
-        out["roofline"] = roofline.dominant_kernel_roofline(lambda: on_main(lambda: eng.step(tiles)), steps=3, vit=eng.vit) if world == 1 else None
+        out["roofline"] = roof
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch, n_local)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
