@@ -21,6 +21,9 @@ def canon(name: str) -> str:
         b = lambda x: "true" if x == "1" else "false"
         epi = m.group(5).replace("n", "-")
         return f"gemm_kernel<{b(m.group(1))}, {b(m.group(2))}, {'bf16' if m.group(3) == 'DF16b' else 'float'}, {b(m.group(4))}, {epi}>"
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([A-Za-z_0-9]+?)I(DF16b|f)EEv", name)      # rocprofv3 leaves __bf16 template arguments mangled
+    if m:
+        return f"{m.group(1)}<{'bf16' if m.group(2) == 'DF16b' else 'float'}>"
     name = re.sub(r"^void\s+", "", name)
     name = name.replace("(anonymous namespace)::", "").replace("gvgemm::", "")
     name = re.sub(r"\(.*\)$", "", name)
