@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_TILE = {("vit_small", "c3"): 113.83, ("vit_small", "c2"): 73.93, ("vit_base", "c3"): 435.56}   # BASELINE.md section 2 / SURVEY 8(a)
 MFMA_BF16_PEAK_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: dense bf16
+MFMA_F32_PEAK_TFLOPS = 157.3                        # MI355X_MICROARCH.md: dense f32 (the fp32 operand mode's MFMA)
 
 
 def synth_tiles(B, size, seed, device):
@@ -44,50 +45,93 @@ def synth_tiles(B, size, seed, device):
     return x.round().clamp(0, 255).to(torch.uint8).to(device)
 
 
-def cpu_baseline(arch, n_local, seconds_budget=25.0):
-    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded
-    sample of the same workload: B=2 tiles per step, K=65536, as many steps as fit."""
+def cpu_baseline(arch, n_local, warmup=2, steps=5):
+    """The oracle (CPU restatement, 'port') timed on this box's host cores with BASELINE.md section 3's protocol:
+    B = 8 tiles per step, K = 65536, 2 warm-up steps, then 5 timed steps (about 15-25 s on the box's 16 cores)."""
     from oracle import step_oracle as so, vit_oracle as vo
     # the GPU box exposes more logical CPUs than its share (16 per GPU); oversubscribing stalls torch
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     torch.set_num_threads(cores)
-    B = 2
+    B = 8
     orc = so.DinoOracle(arch=arch, img_size=224, out_dim=65536, n_local=n_local)
     tiles = vo.synth_tiles(B, 256, seed=1234)
-    orc.step(tiles)                                   # warm-up
-    t0, n = time.time(), 0
-    while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
-        orc.step(tiles); n += 1
+    for _ in range(warmup):
+        orc.step(tiles)
+    t0 = time.time()
+    for _ in range(steps):
+        orc.step(tiles)
     dt = time.time() - t0
-    return {"value": round(B * n / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{n} oracle steps of B={B} tiles (2x224+{n_local}x96 crops, {arch}, K=65536) after 1 warm-up"}
+    return {"value": round(B * steps / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} oracle steps of B={B} tiles (2x224+{n_local}x96 crops, {arch}, K=65536) after {warmup} warm-up steps (BASELINE.md section 3 protocol)"}
 
 
-def launch_children(n: int, argv, child=None, timeout=None):
+def launch_children(n: int, argv, child=None, timeout=None, poll_s: float = 0.2):
     """Start n ranks of this script (or of `child`, a command list: tests use a stub) as CHILD processes with the
     torchrun environment and return (exit code, rank 0's stdout).  The parent never initialises HIP -- nothing is
-    exec'ed from a process that has touched the GPU."""
+    exec'ed from a process that has touched the GPU.  Every child is polled: the first rank that exits non-zero (or the
+    bound `timeout`, default BENCH_LAUNCH_TIMEOUT = 1500 s) ends the job -- the remaining ranks, which would sit in a
+    collective until the backend's own timeout, are killed (the exact Popen objects), that rank's stderr tail is relayed
+    and its code returned (the reference's torchrun does the same for `sbatch-ssl.sh:55`)."""
     import socket
     import subprocess
+    import tempfile
+    import threading
+    if timeout is None:
+        timeout = float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "1500"))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)]
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, rc = "", 0
+        errs.append(tempfile.TemporaryFile("w+"))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=errs[r], text=True))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)     # drains rank 0's pipe while all ranks are polled
+    reader.start()
+    deadline = time.monotonic() + timeout
+    rc, failed = 0, None
     try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for pr in procs:
-            rc = rc or pr.wait(timeout=timeout)
+        while True:
+            codes = [pr.poll() for pr in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed, rc = bad[0][0], bad[0][1]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                failed, rc = -1, 124
+                break
+            time.sleep(poll_s)
     finally:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()               # the exact children started above, never a pattern
-    return rc, out0
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+    reader.join(timeout=10)
+
+    def tail(r, lines=30):
+        errs[r].seek(0)
+        return "".join(errs[r].readlines()[-lines:])
+    if failed is None:
+        sys.stderr.write(tail(0, 200))                      # rank 0's diagnostics, as when its stderr was inherited
+    elif failed < 0:
+        sys.stderr.write(f"bench.py launcher: {n} ranks did not finish within {timeout:.0f} s; killed.  rank 0 stderr tail:\n{tail(0)}")
+    else:
+        sys.stderr.write(f"bench.py launcher: rank {failed} exited with code {rc}; the other ranks were killed.  Its stderr tail:\n{tail(failed)}")
+        rc = rc if rc > 0 else 1                            # a signal (negative Popen code) still reads as failure
+    sys.stderr.flush()
+    for f in errs:
+        f.close()
+    return rc, (out0[0] if out0 else "")
 
 
 def main():
@@ -216,7 +260,8 @@ def main():
                        "tiles_per_gpu": args.batch * args.micro, "micro_batches": args.micro, "global_tiles": args.batch * args.micro * world, "parallelism": f"dp{world}",
                        "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops)},
             "tiles_per_s_per_gpu": round(tiles_s / world, 2),
-            "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[(args.arch, args.config)] / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
+            "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[(args.arch, args.config)] / 1e3
+                                          / (MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_BF16_PEAK_TFLOPS), 4)
             if (args.arch, args.config) in GFLOP_PER_TILE else None,
             "final_loss": round(loss, 4),
         }

@@ -448,12 +448,8 @@ template <int NKT> int launch_fwd(const gv_attention_fwd_args* a, hipStream_t s)
     constexpr int PAIRS = FwdCfg<NKT>::PAIRS;
     constexpr int LDS = PAIRS * 2 * NKT * 16 * 128;
     auto kern = attn_fwd_kernel<NKT>;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { gv_set_error("gv_attention_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        done = true;
-    }
+    static GvLdsOptIn opt_in;
+    if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, LDS, "gv_attention_fwd")) return rc;
     const int n_pairs = a->n_img * a->H;
     hipLaunchKernelGGL(kern, dim3((n_pairs + PAIRS - 1) / PAIRS), dim3(FwdCfg<NKT>::NW * 64), LDS, s, *a, n_pairs);
     GV_LAUNCH_CHECK("gv_attention_fwd");
@@ -464,12 +460,8 @@ template <int NKT> int launch_bwd(const gv_attention_bwd_args* a, hipStream_t s)
     constexpr int NKB = NKT / 2, PAIRS = NKB >= 4 ? 1 : 4 / NKB, NW = NKB * PAIRS, NP = NKT * 16;
     constexpr int LDS = PAIRS * (3 * NP * 128 + NP * (NKT >= 8 ? 128 : 64) + 2 * NP * 4);
     auto kern = attn_bwd_kernel<NKT>;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { gv_set_error("gv_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        done = true;
-    }
+    static GvLdsOptIn opt_in;
+    if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, LDS, "gv_attention_bwd")) return rc;
     const int n_pairs = a->n_img * a->H;
     hipLaunchKernelGGL(kern, dim3((n_pairs + PAIRS - 1) / PAIRS), dim3(NW * 64), LDS, s, *a, n_pairs);
     GV_LAUNCH_CHECK("gv_attention_bwd");

@@ -78,12 +78,8 @@ const char* kernel_name() {
 template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI = -1>
 int launch(const GemmP& p, hipStream_t s) {
     auto kern = gemm_kernel<TA, TB, OutT, ATOMIC, EPI>;
-    static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PCfg::LDS);
-        if (e != hipSuccess) { gv_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
-    }
+    static GvLdsOptIn opt_in;        // > 64 KiB of dynamic LDS: once per kernel instantiation and device
+    if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, PCfg::LDS, "gemm")) return rc;
     // persistent workgroups walk the item list; split-K launches are never persistent (their
     // atomic epilogue reuses the ring): one workgroup per (tile, k-slice)
     const int items = p.tiles_m * p.tiles_n * p.ksplit;
@@ -194,12 +190,8 @@ int launch_dw8(const Dw8P& q, float* C, long ldc, int M, int N, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DW8_LDS);
     }
 #endif
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DW8_LDS);
-        if (e != hipSuccess) { gv_set_error("gemm(dw8): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
-    }
+    static GvLdsOptIn opt_in;
+    if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, DW8_LDS, "gemm(dw8)")) return rc;
     const int th = gvtime::enabled() ? gvtime::begin(SWAP ? "dw8_kernel<true, 0>" : "dw8_kernel<false, 0>", 2.0 * M * N * q.K, 2.0 * q.K * ((double)M + N) + 8.0 * M * N, s) : -1;
     hipLaunchKernelGGL(kern, dim3(q.tiles_p * q.tiles_q * q.ksplit), dim3(512), DW8_LDS, s, q);
     gvtime::end(th, s);
@@ -470,12 +462,8 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
             for (int q = a->n; q <= GV_DW_GROUP_MAX; ++q) G8.tile_base[q] = tb;
             G8.total_tiles = tb;
             if (slab_floats * 4 <= a->workspace_bytes) {
-                static bool attr8 = false;
-                if (!attr8) {
-                    hipError_t e = hipFuncSetAttribute((const void*)dw8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW8_LDS);
-                    if (e != hipSuccess) { gv_set_error("gv_linear_dw_group: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-                    attr8 = true;
-                }
+                static GvLdsOptIn opt_in8;
+                if (int rc = gv_lds_opt_in(opt_in8, (const void*)dw8_group_kernel, DW8_LDS, "gv_linear_dw_group")) return rc;
                 const int th = gvtime::enabled() ? gvtime::begin("dw8_group_kernel", flops, bytes, s) : -1;
                 hipLaunchKernelGGL(dw8_group_kernel, dim3(tb * S), dim3(512), DW8_LDS, s, G8);
                 gvtime::end(th, s);
@@ -532,12 +520,8 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
         slab_floats += (long)ksplit * p.M * p.N;
     }
     GV_REQUIRE(slab_floats * 4 <= a->workspace_bytes, GV_E_SHAPE, "gv_linear_dw_group: workspace too small (%ld bytes needed)", slab_floats * 4);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCfg::LDS);
-        if (e != hipSuccess) { gv_set_error("gv_linear_dw_group: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
-    }
+    static GvLdsOptIn opt_in;
+    if (int rc = gv_lds_opt_in(opt_in, (const void*)gemm_dw_group_kernel, PCfg::LDS, "gv_linear_dw_group")) return rc;
     double flops = 0, bytes = 0;
     for (int q = 0; q < a->n; ++q) { flops += 2.0 * G.prob[q].M * G.prob[q].N * a->K; bytes += 2.0 * a->K * ((double)G.prob[q].M + G.prob[q].N) + 8.0 * G.prob[q].M * G.prob[q].N; }
     const int th = gvtime::enabled() ? gvtime::begin("gemm_dw_group_kernel", flops, bytes, s) : -1;

@@ -25,6 +25,21 @@ void gv_set_error(const char* fmt, ...);
 
 static inline bool gv_aligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
 
+// > 64 KiB of dynamic LDS needs an opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) that is a PER-DEVICE attribute of a
+// kernel: one bit per device ordinal, set with an atomic OR (host threads may race to the same launch site; setting the
+// attribute twice is harmless).  Devices past ordinal 63 set it on every launch.
+struct GvLdsOptIn { unsigned long long done = 0; };
+static inline int gv_lds_opt_in(GvLdsOptIn& st, const void* kern, int bytes, const char* name) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    if (bit && (__atomic_load_n(&st.done, __ATOMIC_ACQUIRE) & bit)) return GV_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { gv_set_error("%s: hipFuncSetAttribute(%d bytes of LDS): %s", name, bytes, hipGetErrorString(e)); return (int)e; }
+    if (bit) __atomic_fetch_or(&st.done, bit, __ATOMIC_RELEASE);
+    return GV_OK;
+}
+
 // ---- wave-level reductions (64-lane wavefront) ------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -108,8 +108,35 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li16 = lane & 15, gq = lane >> 4;
-    const int m0 = blockIdx.x * C::BM;
     const int M = p.M;
+    // MODE_WIDE (N = ncb x 384 output columns): a workgroup owns ONE 384-column block of the output and walks up to ncb
+    // consecutive row panels with it; the ncb workgroups that walk the SAME panels (one per column block) are neighbours on
+    // one XCD (workgroup ids go round-robin over the 8 XCDs: id & 7 is the XCD, id >> 3 the slot on it), so an A panel is
+    // fetched from HBM once and its other ncb - 1 readers hit that XCD's L2 -- the XCD's working set is 32 / ncb panels
+    // + the weights (~2.3 MB), where the round-2 mapping (one workgroup = one panel x all column blocks) re-read every panel
+    // ncb times out of an L2 that 32 different panels (4.3 MB) had already left: 1.41 x the algorithmic traffic on fc1.
+    int m0 = blockIdx.x * C::BM;
+    int cb = 0, nit = 1, first_panel = 0;                 // column block; row panels this workgroup walks, the first one's index
+    if constexpr (MODE == MODE_WIDE) {
+        // (integer division runs on the vector ALU: readfirstlane brings the uniform results back to scalar registers, or every
+        //  row address derived from m0 / cb would occupy vector registers this kernel does not have)
+        const int ncb_ = p.ncb, slot = blockIdx.x >> 3;
+        const int lg = __builtin_amdgcn_readfirstlane(slot / ncb_);
+        const int grp = lg * 8 + (blockIdx.x & 7);
+        cb = slot - lg * ncb_;
+        const int P = __builtin_amdgcn_readfirstlane((M + C::BM - 1) / C::BM), first = grp * ncb_;
+        if (first >= P) return;                           // (whole workgroup: no barrier is pending)
+        nit = P - first < ncb_ ? P - first : ncb_;
+        first_panel = first;
+        m0 = first * C::BM;
+        m0 = m0 < M - C::BM ? m0 : M - C::BM;             // the last panel is shifted back to end at row M (see panel_origin below)
+    }
+    // MODE_WIDE row panels: panel i starts at min(i BM, M - BM) -- every panel holds BM valid rows, so the per-lane source offsets
+    // of the A pieces are the same for all panels (no clamp at M to recompute when the stream moves on to the next panel: that
+    // cost 6 vector registers this kernel does not have -- spills whose reloads drained the counted DMA stream).  The rows the
+    // last two panels share are computed twice, by the same arithmetic in the same order: bit-identical stores.  (The wide
+    // epilogues are pure functions of the row; gv_panel_wide refuses out == resid for the one that reads what it overwrites.)
+    auto panel_origin = [&](int idx) { const int o = idx * C::BM; return o < M - C::BM ? o : M - C::BM; };
 
     // acc[i][j][r]: row m0 + 16 i + (lane & 15), column 16 (NW j + wave) + 4 (lane >> 4) + r
     f32x4 acc[PP ? 1 : FM][NF];
@@ -131,13 +158,18 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     // (wave a + pc) 8 .. + 7 (clamped at M), 128 B each, 16-B chunk XOR (row & 7); W block piece pc: natural -- weight rows
     // (wave 2 + pc) 8 .. + 7 of the block; transposed -- reduction rows (wave 2 + pc) 4 .. + 3, 256 B of the block's columns each
     unsigned voffA[PP ? C::A_PPW : 1], voffW[2];
-    if constexpr (PP) {
+    auto a_offsets = [&](unsigned (&vo)[PP ? C::A_PPW : 1], int origin) {      // per-lane byte offsets of a panel's A pieces from its first row
 #pragma unroll
         for (int pc = 0; pc < C::A_PPW; ++pc) {
             const int rr = (wave * C::A_PPW + pc) * 8 + (lane >> 3);
-            int row = m0 + rr; row = row < M ? row : M - 1;
-            voffA[pc] = (unsigned)(((long)(row - m0) * p.lda + (((lane & 7) ^ (rr & 7)) << 3)) * 2);
+            int row;
+            if constexpr (MODE == MODE_WIDE) row = origin + (rr < C::BM ? rr : rr - C::BM);      // surplus staged rows (never stored): any row of the panel
+            else { row = origin + rr; row = row < M ? row : M - 1; }
+            vo[pc] = (unsigned)(((long)(row - origin) * p.lda + (((lane & 7) ^ (rr & 7)) << 3)) * 2);
         }
+    };
+    if constexpr (PP) {
+        a_offsets(voffA, m0);
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
             if constexpr (!TB) {
@@ -149,8 +181,9 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
             }
         }
     }
-    const unsigned long long baseA = (unsigned long long)(p.A + (long)m0 * p.lda);
-    unsigned long long baseW = (unsigned long long)p.W;           // + the column block (MODE_WIDE)
+    unsigned long long baseA = (unsigned long long)(p.A + (long)m0 * p.lda);         // (advances panel by panel in MODE_WIDE)
+    const unsigned long long baseW = (unsigned long long)p.W
+        + (unsigned long long)cb * (unsigned long long)(TB ? (long)PN * 2 : (long)PN * p.ldw * 2);     // this workgroup's column block
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     auto issue = [&](int t) {
         GV_LDS char* st = smem + (t & 1) * C::STAGE;
@@ -161,43 +194,41 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     };
     // ---- PP: pieces of a K-tile in DMA-stream order: A (a = A_PPW per wave), W0, W1, W2 (two per wave each); n = a + 6
     constexpr int PA = C::A_PPW, PN_T = PA + 6;
-    // Tile nt (the one the stream reaches behind a block's last): MODE_WIDE with another column block to come -- that block's
-    // tile 0 (same A rows from k = 0, the next 384 weight rows), so the stream runs on across the block boundary; otherwise a
-    // re-read of the last tile that is never consumed (keeps the counted waits uniform).  Tile nt + 1 is never issued: the
-    // last tile's phases run the TAIL variant below.
-    // A phase resolves "past the end" once, with scalar selects, for the pieces it issues: (uc, bw) = the tile's k index and
-    // weight base, uc_past / bw_past (set per block) for tile nt.
-    const unsigned long long wstep = (unsigned long long)(TB ? (long)PN * 2 : (long)PN * p.ldw * 2);    // bytes from one column block's weights to the next
+    // Tile nt (the one the stream reaches behind a panel's last): MODE_WIDE with another row panel to come -- that panel's
+    // tile 0 (the next BM rows of A from k = 0, the same 384 weight rows), so the stream runs on across the panel boundary
+    // and the panel's epilogue covers its latency (the epilogue's image lives in stage 1 and behind it: the k-loop ends in
+    // stage 1, nt is even); otherwise a re-read of the last tile that is never consumed (keeps the counted waits uniform).
+    // Tile nt + 1 is never issued: the last tile's phases run the TAIL variant below.
+    // A phase resolves "past the end" once, with scalar selects, for the pieces it issues: (uc, ba) = the tile's k index and A
+    // base; uc_past / baseA_past (set per panel) describe tile nt.  The per-lane A offsets are the same for every panel.
     int uc_past = nt - 1;
-    unsigned long long bw_past = baseW;
-    auto issue_x = [&](auto Xc, int u, int uc, unsigned long long bw) {
+    unsigned long long baseA_past = baseA;
+    auto issue_x = [&](auto Xc, int u, int uc, unsigned long long ba) {
         constexpr int X = decltype(Xc)::value;
         const unsigned st = lds0 + (u & 1) * C::STAGE;
         if constexpr (X < PA) {
-            glds16_s<0>(baseA + (unsigned long long)uc * (BK * 2), voffA[X], st + (wave * PA + X) * 1024);
+            glds16_s<0>(ba + (unsigned long long)uc * (BK * 2), voffA[X], st + (wave * PA + X) * 1024);
         } else {
             constexpr int b = (X - PA) / 2, pc = (X - PA) % 2;
             const unsigned dst = st + C::A_BYTES + b * C::W_BLOCK + (wave * 2 + pc) * 1024;
-            if constexpr (!TB) glds16_s<0>(bw + ((unsigned long long)(128 * b) * p.ldw + (unsigned long long)uc * BK) * 2, voffW[pc], dst);
-            else glds16_s<b * 256>(bw + (unsigned long long)uc * BK * p.ldw * 2, voffW[pc], dst);
+            if constexpr (!TB) glds16_s<0>(baseW + ((unsigned long long)(128 * b) * p.ldw + (unsigned long long)uc * BK) * 2, voffW[pc], dst);
+            else glds16_s<b * 256>(baseW + (unsigned long long)uc * BK * p.ldw * 2, voffW[pc], dst);
         }
     };
-    if constexpr (PP) static_for<0, PN_T>([&](auto X) { issue_x(X, 0, 0, baseW); }); else
+    if constexpr (PP) static_for<0, PN_T>([&](auto X) { issue_x(X, 0, 0, baseA); }); else
     issue(0);
-    // MODE_WIDE walks the 384-column blocks of the output with the same row panel: the A rows are staged again per block (from
-    // L2), the block's first ring stage is requested before the previous block's epilogue (whose image lives in stage 1 and
-    // behind it: the k-loop ends in stage 1, nt is even) so the epilogue covers its latency.
-    const int ncb = MODE == MODE_WIDE ? p.ncb : 1;
     float s_dg[3][2], s_db[3][2], s_g[3][2];          // backward: column sums over this workgroup's rows
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int e = 0; e < 2; ++e) { s_dg[c][e] = 0.f; s_db[c][e] = 0.f; s_g[c][e] = 0.f; }
-    for (int cb = 0; cb < ncb; ++cb) {
+    for (int it = 0; it < nit; ++it) {
+    int m0_next = m0;
     if constexpr (PP) {
-        const bool has_next = MODE == MODE_WIDE && cb + 1 < ncb;
+        const bool has_next = MODE == MODE_WIDE && it + 1 < nit;
         uc_past = has_next ? 0 : nt - 1;
-        bw_past = has_next ? baseW + wstep : baseW;
+        m0_next = has_next ? panel_origin(first_panel + it + 1) : m0;
+        baseA_past = (unsigned long long)(p.A + (long)m0_next * p.lda);
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -205,7 +236,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc8[b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // prologue: tile 0 is out (start of the kernel / before the previous block's epilogue); A, W0, W1 of tile 1 follow
-        static_for<0, PA + 4>([&](auto X) { issue_x(X, 1, 1, baseW); });
+        static_for<0, PA + 4>([&](auto X) { issue_x(X, 1, 1, baseA); });
         wait_vmcnt<PN_T + 2>();                               // A and W0 of tile 0 landed
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -239,18 +270,17 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                     for (int i = 0; i < FMH; ++i) fa[ks][i] = read_frag<false, C::A_ROWS, BK>(st, f0 + i, ks, lane);
                 const bool past = t + 1 >= nt;
                 const int uc = past ? uc_past : t + 1;
-                const unsigned long long bw = past ? bw_past : baseW;
-                static_for<PA + 4, PN_T>([&](auto X) { issue_x(X, t + 1, uc, bw); }); wait_vmcnt<PN_T + 2>();
+                static_for<PA + 4, PN_T>([&](auto X) { issue_x(X, t + 1, uc, baseA); }); wait_vmcnt<PN_T + 2>();
             } else {
                 const bool past = t + 2 >= nt;
                 const int uc = past ? uc_past : t + 2;
-                const unsigned long long bw = past ? bw_past : baseW;
+                const unsigned long long ba = past ? baseA_past : baseA;
                 if constexpr (J == 1) {
                     if (tail) wait_vmcnt<PN_T>();
-                    else { static_for<0, PA>([&](auto X) { issue_x(X, t + 2, uc, bw); }); wait_vmcnt<PN_T + PA>(); }
+                    else { static_for<0, PA>([&](auto X) { issue_x(X, t + 2, uc, ba); }); wait_vmcnt<PN_T + PA>(); }
                 } else {
                     if (tail) wait_vmcnt<4>();
-                    else { static_for<PA, PA + 4>([&](auto X) { issue_x(X, t + 2, uc, bw); }); wait_vmcnt<PN_T + 2>(); }
+                    else { static_for<PA, PA + 4>([&](auto X) { issue_x(X, t + 2, uc, ba); }); wait_vmcnt<PN_T + 2>(); }
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);               // this segment's reads are retired before its barrier
@@ -330,15 +360,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
             for (int j = 0; j < 2; ++j)
                 bias8[b][j] = (PP && p.bias) ? *(const f32x4*)(p.bias + cb * PN + 128 * b + 16 * (2 * wn + j) + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (MODE == MODE_WIDE) {
-        if (cb + 1 < ncb) {                   // next block's weights; its first stage goes out now (stage 0 was last read at step nt - 2)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) if constexpr (!PP) srcW[j].setup(p.W, p.ldw, (cb + 1) * PN + 128 * j, n_total, wave, lane);
-            if constexpr (PP) baseW += wstep;     // (its tile 0 went out as tile nt of this block's stream)
-            else
-            issue(0);
-        }
-    }
+    static_assert(MODE != MODE_WIDE || PP, "MODE_WIDE runs on the ping-pong k-loop only (gv_panel_wide requires K % 128 == 0)");
     // per-lane column constants of the row phase: lane owns columns (c * 64 + lane) * 2 + {0, 1}, c = 0..2
     float gm[3][2], bt[3][2];
     const bool ln = MODE == MODE_BWD || (MODE == MODE_FWD && p.gamma != nullptr);
@@ -543,7 +565,10 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         }
         __syncthreads();                                          // image free for the next pass / the reduction below
     }
-    }   // column blocks
+    if constexpr (MODE == MODE_WIDE) {                            // next row panel (its tile 0 went out as tile nt of this panel's stream)
+        m0 = m0_next; baseA = baseA_past;
+    }
+    }   // row panels (MODE_WIDE)
 
     if constexpr (MODE == MODE_BWD) {
         // column sums over this workgroup's rows -> partials[blockIdx][3][384] (gv_ln_finalize folds them)
@@ -578,20 +603,28 @@ int pick_fm(int M) {
     return 12;
 }
 
+// MODE_WIDE launch geometry (see the kernel's id mapping): groups of ncb sibling workgroups, ceil(groups / 8) per XCD
+int wide_grid(int M, int BM, int ncb) {
+    const int P = (M + BM - 1) / BM, groups = (P + ncb - 1) / ncb;
+    return 8 * ncb * ((groups + 7) / 8);
+}
+// ... and the smallest supported FM whose launch is one round of workgroups (<= 256); 12 (several rounds) for larger M
+int pick_fm_wide(int M, int ncb) {
+    for (int fm : FM_SET8) if (wide_grid(M, 16 * fm, ncb) <= 256) return fm;
+    return 12;
+}
+
 template <int FM, int NW, int BK, bool TB, int MODE, int EP = 0, int PP = 0>
 int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
     auto kern = panel_kernel<FM, NW, BK, TB, MODE, EP, PP>;
     using C = PC<FM, NW, BK>;
     constexpr int LDS_BYTES = MODE == MODE_WIDE ? C::LDS_WIDE : C::LDS;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { gv_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
-    }
-    static char kname[96] = "";
-    if (!kname[0]) snprintf(kname, sizeof(kname), "panel_kernel<%d, %d, %d, %s, %d, %d, %d>", FM, NW, BK, TB ? "true" : "false", MODE, EP, PP);   // as rocprofv3 prints it
-    const int grid = (p.M + C::BM - 1) / C::BM;
+    static GvLdsOptIn opt_in;
+    if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, LDS_BYTES, name)) return rc;
+    struct Name { char s[96]; Name() { snprintf(s, sizeof(s), "panel_kernel<%d, %d, %d, %s, %d, %d, %d>", FM, NW, BK, TB ? "true" : "false", MODE, EP, PP); } };
+    static const Name kn;                                           // as rocprofv3 prints it (initialised once, thread-safe)
+    const char* kname = kn.s;
+    const int grid = MODE == MODE_WIDE ? wide_grid(p.M, C::BM, p.ncb) : (p.M + C::BM - 1) / C::BM;
     // algorithmic bytes: forward  A row + f32 residual in + f32 row out + bf16 normalised row out + stats;
     // backward  dY row + f32 x row + f32 g in / out + bf16 g out; + the weight once
     // wide: A row + the bf16 output row (+ the saved / re-read pre-activation row)
@@ -609,7 +642,7 @@ template <bool TB, int MODE, int EP = 0>
 int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
     // the ping-pong k-loop walks K-tiles in pairs (static ring stage): K % 128 == 0; other depths keep the one-stage-ahead loop
     if (p.K % 128 == 0) {
-        switch (pick_fm(p.M)) {
+        switch (MODE == MODE_WIDE ? pick_fm_wide(p.M, p.ncb) : pick_fm(p.M)) {
             case 4: return launch_panel<4, 8, 64, TB, MODE, EP, 1>(p, s, name);
             case 7: return launch_panel<7, 8, 64, TB, MODE, EP, 1>(p, s, name);
             case 9: return launch_panel<9, 8, 64, TB, MODE, EP, 1>(p, s, name);
@@ -617,6 +650,8 @@ int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
             default: return launch_panel<12, 8, 64, TB, MODE, EP, 1>(p, s, name);
         }
     }
+    if constexpr (MODE == MODE_WIDE) return -1;                     // (gv_panel_wide admits K % 128 == 0 only)
+    else
     switch (pick_fm(p.M)) {
         case 4: return launch_panel<4, 8, 64, TB, MODE, EP>(p, s, name);
         case 7: return launch_panel<7, 8, 64, TB, MODE, EP>(p, s, name);
@@ -636,6 +671,7 @@ int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
     if (a->alpha != 0.f && a->alpha != 1.f) return -1;
     if (a->c_is_f32) {      // x + Linear(a) with an f32 residual stream, where no fused LayerNorm kernel exists for the width
         if (a->trans_b || a->epilogue != (GV_EPI_BIAS | GV_EPI_RESID) || a->ldr % 2 != 0) return -1;
+        if ((const void*)a->resid == (const void*)a->C) return -1;      // in place: the rows the last two panels share would be updated twice
         PanelP q{};
         q.A = (const bf16*)a->A; q.W = (const bf16*)a->B; q.M = a->M; q.K = a->K; q.lda = a->lda; q.ldw = a->ldb;
         q.bias = a->bias; q.out = (float*)a->C; q.ldo = a->ldc; q.resid = a->resid; q.ldr = a->ldr; q.row_scale = a->row_scale;

@@ -148,11 +148,20 @@ def scan_slides(root: str, target: Optional[str] = None):
 
 
 def select_fold(slides, test_fold, train: bool):
-    """Reference fold rule (datasets.py:28-120 test_fold): training uses the slides whose fold differs from
-    ``test_fold``, evaluation the slides in it; slides without a fold column belong to both."""
-    tf = "test" if test_fold == 0 else str(test_fold)
-    keep = [s for s in slides if s[3] is None or ((s[3] != tf) if train else (s[3] == tf))]
-    return keep or slides
+    """Reference fold rule (datasets.py:274-287): TRAINING uses every fold except ``test_fold`` and never the 'test' / 'val'
+    folds (``test_fold == -1``: every fold but those two); EVALUATION uses ``[test_fold, 'val']`` (nothing for -1).  Fold 0 is
+    spelled 'test' in the slide tables (datasets.py:290-291).  Slides of a root without a fold column (fold None) belong to
+    both sets.  An empty selection raises: handing back all slides instead would let the evaluation AUC and the
+    model_best choice be computed on training slides."""
+    tf = None if test_fold in (-1, "-1") else ("test" if test_fold in (0, "0", "test") else str(test_fold))
+    if train:
+        keep = [s for s in slides if s[3] is None or s[3] not in (tf, "test", "val")]
+    else:
+        keep = [s for s in slides if s[3] is None or (tf is not None and s[3] in (tf, "val"))]
+    if not keep:
+        raise ValueError(f"test_fold={test_fold}: no {'training' if train else 'evaluation'} slides (folds present: "
+                         f"{sorted({str(s[3]) for s in slides})})")
+    return keep
 
 
 class TileFolder:

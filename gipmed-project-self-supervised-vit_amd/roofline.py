@@ -9,7 +9,7 @@ written once).  The dominant kernel is the row with the largest summed time.  Wh
 from its arithmetic intensity against the machine balance (2500 TFLOP/s / 8 TB/s = 312 FLOP/B): below it the
 kernel is priced against HBM (achieved = algorithmic bytes / time), above it against the dense bf16 MFMA
 peak; both fractions are reported.  The average launch duration must agree with what rocprofv3 --kernel-trace
---stats reports for the same kernel name (profiles/).  `traffic` is the measured HBM bytes per launch of that
+--stats reports for the same kernel name (profiles/*_step_kernel_stats.csv for the headline, *_exclusive.csv for `exclusive`).  `traffic` is the measured HBM bytes per launch of that
 kernel from the committed PMC passes, looked up in profiles/*_hbm_traffic_per_kernel.json."""
 from __future__ import annotations
 
@@ -54,40 +54,42 @@ def _timed_rows(step_fn, steps):
     return rows
 
 
-def dominant_kernel_roofline(step_fn, steps: int = 3, vit=None):
-    """`vit`: the engine's VitRunner.  The step overlaps the weight-gradient GEMMs and the teacher
-    forward with the main stream (engine.py); a kernel that shares the chip is stretched by its
-    neighbours, so the roofline figure is taken from steps run with that side stream switched off
-    (one kernel on the chip at a time, what `GIPVIT_DW_STREAM=0 rocprofv3 --kernel-trace --stats`
-    reports); the same kernel's duration inside the overlapped step is given as `in_step`."""
-    in_step = None
-    if vit is not None and vit.side is not None:
-        shared = {r["kernel"]: r for r in _timed_rows(step_fn, steps)}
-        keep, vit.side = vit.side, None
-        try:
-            rows = _timed_rows(step_fn, steps)
-        finally:
-            vit.side = keep
-        r = shared.get(rows[0]["kernel"])
-        if r is not None:
-            in_step = {"avg_launch_us": round(r["seconds"] / r["launches"] * 1e6, 2), "achieved": round(r["flops"] / r["seconds"] / 1e12, 1),
-                       "note": "same kernel while the side stream's kernels share the chip"}
-    else:
-        rows = _timed_rows(step_fn, steps)
-    table = [{"kernel": r["kernel"], "launches_per_step": round(r["launches"] / steps, 2), "avg_us": round(r["seconds"] / r["launches"] * 1e6, 2),
-              "ms_per_step": round(r["seconds"] / steps * 1e3, 3), "tflops": round(r["flops"] / r["seconds"] / 1e12, 1),
-              "gbs": round(r["bytes"] / r["seconds"] / 1e9, 0)} for r in rows]
-    d = rows[0]
+def _figures(d, steps):
     tf, gbs = d["flops"] / d["seconds"] / 1e12, d["bytes"] / d["seconds"] / 1e9
     peak_tf = PEAK_F32_MFMA_TFLOPS if "f32_kernel" in d["kernel"] else PEAK_BF16_TFLOPS
     hbm_bound = d["bytes"] > 0 and d["flops"] / d["bytes"] < peak_tf * 1e3 / PEAK_HBM_GBS
-    traffic, src = _traffic_for(d["kernel"])
     head = ({"bound": "hbm", "kernel": d["kernel"], "achieved": round(gbs, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
             if hbm_bound else
             {"bound": "mfma", "kernel": d["kernel"], "achieved": round(tf, 1), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4)})
     return {**head, "mfma_frac": round(tf / peak_tf, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
             "flop_per_byte": round(d["flops"] / d["bytes"], 1) if d["bytes"] > 0 else None,
             "avg_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 2),
-            "traffic": traffic, "traffic_source": src,
             "launches_per_step": round(d["launches"] / steps, 2), "avg_launch_us": round(d["seconds"] / d["launches"] * 1e6, 2),
-            "avg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3), "timed_steps": steps, "in_step": in_step, "gemm_kernels": table}
+            "avg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
+
+
+def dominant_kernel_roofline(step_fn, steps: int = 3, vit=None):
+    """`vit`: the engine's VitRunner.  The headline figures are those of the TIMED configuration: the step as bench.py
+    times it, with the side stream's kernels (weight gradients, the teacher's forward) sharing the chip -- a kernel that
+    shares CUs is stretched by its neighbours, and that is the duration the step pays.  `exclusive` holds the same kernel
+    with the side stream switched off (one kernel on the chip at a time: what `GIPVIT_DW_STREAM=0 rocprofv3 --kernel-trace
+    --stats` reports, profiles/*_step_kernel_stats_exclusive.csv) -- the figure that says how good the kernel itself is."""
+    rows = _timed_rows(step_fn, steps)
+    d = rows[0]
+    exclusive = None
+    if vit is not None and vit.side is not None:
+        keep, vit.side = vit.side, None
+        try:
+            alone = {r["kernel"]: r for r in _timed_rows(step_fn, steps)}
+        finally:
+            vit.side = keep
+        if d["kernel"] in alone:
+            exclusive = _figures(alone[d["kernel"]], steps)
+            exclusive["note"] = "same kernel with the side stream off: one kernel on the chip at a time"
+    table = [{"kernel": r["kernel"], "launches_per_step": round(r["launches"] / steps, 2), "avg_us": round(r["seconds"] / r["launches"] * 1e6, 2),
+              "ms_per_step": round(r["seconds"] / steps * 1e3, 3), "tflops": round(r["flops"] / r["seconds"] / 1e12, 1),
+              "gbs": round(r["bytes"] / r["seconds"] / 1e9, 0)} for r in rows]
+    traffic, src = _traffic_for(d["kernel"])
+    return {**_figures(d, steps), "configuration": "in_step (the timed configuration: side stream on)" if exclusive is not None else "in_step",
+            "traffic": traffic, "traffic_source": src, "traffic_measured_in": "profiles",
+            "timed_steps": steps, "exclusive": exclusive, "gemm_kernels": table}

@@ -18,6 +18,8 @@ def scaled_lr(lr, lr_base, batch_size, world_size, lr_base_size=256, lr_base_sca
 class LrSchedule:
     def __init__(self, lr, sched="cosine", epochs=300, warmup_epochs=5, warmup_lr=1e-5, min_lr=0.0, updates_per_epoch=1,
                  decay_epochs=90, decay_rate=0.1, on_updates=False):
+        if sched not in ("cosine", "step"):
+            raise ValueError(f"sched {sched!r}: 'cosine' or 'step' (nothing is substituted for timm's other schedulers)")
         self.lr, self.sched, self.E, self.WE, self.wlr, self.min_lr = lr, sched, epochs, warmup_epochs, warmup_lr, min_lr
         self.upe, self.decay_epochs, self.decay_rate, self.on_updates = max(1, updates_per_epoch), decay_epochs, decay_rate, on_updates
 
@@ -27,9 +29,7 @@ class LrSchedule:
             return self.wlr + (self.lr - self.wlr) * t / self.WE
         if self.sched == "cosine":
             return self.min_lr + 0.5 * (self.lr - self.min_lr) * (1 + math.cos(math.pi * min(t, self.E) / self.E))
-        if self.sched == "step":
-            return self.lr * (self.decay_rate ** int(t // self.decay_epochs))
-        return self.lr
+        return self.lr * (self.decay_rate ** int(t // self.decay_epochs))          # "step"
 
 
 def cosine_between(start: float, end: float, step: int, total: int) -> float:

@@ -55,22 +55,32 @@ def dino_curve_schedule(step: int, steps: int = 100, per_epoch: int = 25, B: int
                 train_last_layer=epoch >= 1)
 
 
-def dino_tiny_curve(steps=100):
-    """100 DINO steps (the length north_star gates at 1e-3): ViT-T, 2x224 + 8x96 crops of eight fresh 256-px tiles per
-    step, K = 4096, clip 3.0, the recipe's schedules above.  Keeps the loss curve, the centre and slices of the
-    student / teacher weights at the end."""
-    orc = so.DinoOracle(arch="vit_tiny", img_size=224, out_dim=4096, seed=0, clip_grad=3.0)
+def _dino_curve(arch, fname, steps, B=8):
+    orc = so.DinoOracle(arch=arch, img_size=224, out_dim=4096, seed=0, clip_grad=3.0)
     curve, gnorm = [], []
     for t in range(steps):
-        r = orc.step(vo.synth_tiles(8, 256, seed=5000 + t), **dino_curve_schedule(t, steps))
+        r = orc.step(vo.synth_tiles(B, 256, seed=5000 + t), **dino_curve_schedule(t, steps, B=B))
         curve.append(r["loss"]); gnorm.append(r["grad_norm"])
-    np.savez_compressed(os.path.join(OUT, "dino_tiny_curve.npz"), curve=np.array(curve), grad_norm=np.array(gnorm),
+    np.savez_compressed(os.path.join(OUT, fname), curve=np.array(curve), grad_norm=np.array(gnorm),
                         center=orc.center.numpy()[0, :512],
                         s_qkv0=orc.p["blocks.0.attn.qkv.weight"].numpy()[:8, :32], t_qkv0=orc.tp["blocks.0.attn.qkv.weight"].numpy()[:8, :32],
                         s_fc2_11=orc.p["blocks.11.mlp.fc2.weight"].numpy()[:8, :32], t_fc2_11=orc.tp["blocks.11.mlp.fc2.weight"].numpy()[:8, :32],
                         s_last=orc.hp["last_layer.weight_v"].numpy()[:8, :32], t_last=orc.thp["last_layer.weight_v"].numpy()[:8, :32],
                         s_pos=orc.p["pos_embed"].numpy()[0, :4, :32], s_mlp4=orc.hp["mlp.4.weight"].numpy()[:8, :32],
-                        init_qkv0=vo.init_vit("vit_tiny", 224, 0, 0)["blocks.0.attn.qkv.weight"].numpy()[:8, :32])
+                        init_qkv0=vo.init_vit(arch, 224, 0, 0)["blocks.0.attn.qkv.weight"].numpy()[:8, :32])
+
+
+def dino_tiny_curve(steps=100):
+    """100 DINO steps (the length north_star gates at 1e-3): ViT-T, 2x224 + 8x96 crops of eight fresh 256-px tiles per
+    step, K = 4096, clip 3.0, the recipe's schedules above.  Keeps the loss curve, the centre and slices of the
+    student / teacher weights at the end."""
+    _dino_curve("vit_tiny", "dino_tiny_curve.npz", steps)
+
+
+def dino_small_curve(steps=100):
+    """The same 100 recipe steps on the HEADLINE architecture (ViT-S/16: the width whose Linear + LayerNorm products run
+    fused in csrc/panel.hip), eight fresh tiles per step.  About ten minutes of CPU, run once; the fixture is committed."""
+    _dino_curve("vit_small", "dino_small_curve.npz", steps)
 
 
 if __name__ == "__main__":

@@ -51,11 +51,7 @@ def test_supervised_step_parity(dev):
     assert float((eng.logits.cpu() - logits_r).abs().max()) <= 2e-2 * max(scale, 1.0)
     assert abs(float(eng.loss) - float(loss_r)) <= 1e-3
     _check_grads(eng.grads(), grads_r)
-    # a few optimizer steps: loss trajectory
-    for i in range(5):
-        r = orc.step(tiles, tgt)
-        l = eng.step(tiles.to(dev), tgt.to(dev))
-        assert abs(float(l) - r["loss"]) <= 5e-3, (i, float(l), r["loss"])   # lr 1e-3 on 8 tiles: Adam's sign-like first updates amplify bf16 noise; the 100-step curves hold 1e-3
+    # (the optimizer trajectory is held to 1e-3 over 100 steps by test_golden_supervised_curve)
 
 
 @gpu
@@ -82,21 +78,15 @@ def test_dino_step_parity(dev, n_local):
     assert abs(float(eng.loss) - float(loss_r)) <= 1e-3, (float(eng.loss), float(loss_r))
     assert _rel(eng.center_sum, bsum[0]) < 1e-2
     worst, gn = _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))
-    # then full steps (optimizer + EMA + center) stay on the oracle's trajectory.  lr 5e-5 here: Adam's first updates are
-    # lr * sign(g) for EVERY weight, so each near-zero gradient component whose sign bf16 noise flips moves a weight by
-    # 2 lr -- at the 5e-4 the oracle was built with (128 x the recipe's 5e-4 * B / 256 for two tiles) that alone measured
-    # |dloss| 8.4e-3 by step 2 (gpurun_out/r2_t1.log); the effect is linear in lr.  The recipe's schedules are held to 1e-3
-    # over 100 steps by test_golden_dino_curve.
+    # one full step at the oracle's own lr: the centre update and the teacher EMA (exact functions of the step's inputs; the
+    # optimizer TRAJECTORY is held to 1e-3 over 100 recipe steps by test_golden_dino_curve on both ViT-T and the fused ViT-S path --
+    # a 3-step trajectory at a hand-picked lr used to stand here)
     eng.t = 0
-    for i in range(3):
-        r = orc.step(tiles, lr=5e-5)
-        l = eng.step(tiles.to(dev), lr=5e-5)
-        assert abs(float(l) - r["loss"]) <= 2e-3, (i, float(l), r["loss"])
+    orc.step(tiles); eng.step(tiles.to(dev))
     torch.cuda.synchronize()
     assert _rel(eng.center, orc.center[0]) < 1e-2
-    sd, td = eng.backbone_state_dict(), eng.backbone_state_dict(teacher=True)
+    td = eng.backbone_state_dict(teacher=True)
     for k in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "pos_embed", "norm.weight"):
-        assert _rel(sd[k], orc.p[k]) < 5e-3, k
         assert _rel(td[k], orc.tp[k]) < 1e-3, k
 
 
@@ -236,9 +226,12 @@ def test_golden_supervised_curve(dev):
 
 
 @gpu
-def test_golden_dino_curve(dev):
-    """north_star: "loss-vs-step curve matching the CPU reference to 1e-3 over 100 steps" on the DINO step itself.
-    tests/golden/dino_tiny_curve.npz (oracle/make_golden.py): ViT-T, 2x224 + 8x96 crops of eight fresh tiles per step,
+@pytest.mark.parametrize("arch,D,fixture", [("vit_tiny", 192, "dino_tiny_curve.npz"), ("vit_small", 384, "dino_small_curve.npz")])
+def test_golden_dino_curve(dev, arch, D, fixture):
+    """north_star: "loss-vs-step curve matching the CPU reference to 1e-3 over 100 steps" on the DINO step itself, on the
+    unfused path (ViT-T: 128x128-tile GEMMs + stand-alone LayerNorm) AND on the headline path (ViT-S: the full-row Linear +
+    LayerNorm kernels of csrc/panel.hip forward and backward, wide products, grouped weight gradients).
+    tests/golden/dino_{tiny,small}_curve.npz (oracle/make_golden.py): 2x224 + 8x96 crops of eight fresh tiles per step,
     K = 4096, clip 3.0, and the recipe's schedules -- lr warm-up + cosine, weight decay 0.04 -> 0.4, teacher momentum
     0.996 -> 1, teacher temperature 0.04 -> 0.07, last layer frozen during the first 25 steps.  Also checks
     the centre, the teacher (EMA) and the student weights after step 100."""
@@ -247,10 +240,11 @@ def test_golden_dino_curve(dev):
     from gipvit.engine import DinoEngine
     from oracle import vit_oracle as vo
     from oracle.make_golden import dino_curve_schedule
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "dino_tiny_curve.npz"))
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
     steps = len(gold["curve"])
-    eng = DinoEngine(arch="vit_tiny", img_size=224, out_dim=4096, batch=8, clip_grad=3.0, device=dev)
-    eng.load_state(vo.init_vit("vit_tiny", 224, 0, seed=0), vo.init_dino_head(192, 4096, seed=1))
+    eng = DinoEngine(arch=arch, img_size=224, out_dim=4096, batch=8, clip_grad=3.0, device=dev)
+    assert eng.vit.fused == (arch == "vit_small")
+    eng.load_state(vo.init_vit(arch, 224, 0, seed=0), vo.init_dino_head(D, 4096, seed=1))
     curve = []
     for t in range(steps):
         sch = dino_curve_schedule(t, steps)
@@ -259,7 +253,7 @@ def test_golden_dino_curve(dev):
     torch.cuda.synchronize()
     curve = np.array([float(c) for c in curve])
     err = np.abs(curve - gold["curve"])
-    print(f"[golden DINO curve] {steps} steps, max |dloss| {err.max():.2e} at step {int(err.argmax())}, final {curve[-1]:.5f} vs {gold['curve'][-1]:.5f}")
+    print(f"[golden DINO curve {arch}] {steps} steps, max |dloss| {err.max():.2e} at step {int(err.argmax())}, final {curve[-1]:.5f} vs {gold['curve'][-1]:.5f}")
     assert float(err.max()) <= 1e-3, (float(err.max()), int(err.argmax()), curve[:4], gold["curve"][:4])
     assert _rel(eng.center[:512], torch.from_numpy(gold["center"])) < 1e-2
     sb, tb = eng.backbone_state_dict(), eng.backbone_state_dict(teacher=True)
@@ -275,6 +269,37 @@ def test_golden_dino_curve(dev):
                      (sh["mlp.4.weight"], "s_mlp4")):
         assert _rel(got[:8, :32], torch.from_numpy(gold[key])) < 2e-3, key
     assert _rel(sb["pos_embed"][0, :4, :32], torch.from_numpy(gold["s_pos"])) < 2e-3
+
+
+@gpu
+def test_headline_100_steps_bf16_vs_fp32_mode(dev):
+    """The same 100 recipe steps at the HEADLINE size -- ViT-S/16, 64 tiles, 2x224 + 8x96 crops, K = 65536 -- where the CPU oracle
+    cannot follow: the bf16 training path against this build's fp32 operand mode (itself held to 1e-4 / 1e-6 against the oracle,
+    tests/test_fp32_gpu.py).  max |dloss| <= 1e-3 over the curve."""
+    import numpy as np
+    from gipvit.engine import DinoEngine
+    from oracle import vit_oracle as vo
+    from oracle.make_golden import dino_curve_schedule
+    B, steps = 64, 100
+    engs = [DinoEngine(arch="vit_small", img_size=224, out_dim=65536, batch=B, clip_grad=3.0, device=dev, precision=pr) for pr in ("bf16", "fp32")]
+    bb, hd = vo.init_vit("vit_small", 224, 0, seed=0), vo.init_dino_head(384, 65536, seed=1)
+    for e in engs:
+        e.load_state(bb, hd)
+    curves = [[], []]
+    for t in range(steps):
+        sch = dino_curve_schedule(t, steps, B=B)
+        tll = sch.pop("train_last_layer")
+        tiles = vo.synth_tiles(B, 256, seed=9000 + t).to(dev)
+        for e, c in zip(engs, curves):
+            e.train_last_layer = tll
+            c.append(e.step(tiles, **sch).clone())
+    torch.cuda.synchronize()
+    a, b = (np.array([float(x) for x in c]) for c in curves)
+    err = np.abs(a - b)
+    print(f"[headline bf16 vs fp32 mode] {steps} steps, max |dloss| {err.max():.2e} at step {int(err.argmax())}, final {a[-1]:.5f} vs {b[-1]:.5f}, start {a[0]:.5f}")
+    assert abs(a[-1] - a[0]) > 1e-2                              # the curve moves
+    assert float(err.max()) <= 1e-3, (float(err.max()), int(err.argmax()))
+    assert _rel(engs[0].center, engs[1].center) < 1e-2
 
 
 @gpu
@@ -370,7 +395,8 @@ def test_drop_path_dino_parity(dev):
     gradients) in the DINO step: student with per-crop-image factors, teacher without."""
     from gipvit.engine import DinoEngine
     from oracle import step_oracle as so, vit_oracle as vo
-    K, B = 2048, 2
+    K, B = 2048, 8
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
     orc = so.DinoOracle(arch="vit_small", img_size=224, out_dim=K, seed=0, lr=5e-4, wd=0.04)
     eng = DinoEngine(arch="vit_small", img_size=224, out_dim=K, batch=B, lr=5e-4, weight_decay=0.04, device=dev)
     eng.load_state(orc.p, orc.hp)
@@ -382,6 +408,6 @@ def test_drop_path_dino_parity(dev):
     eng.set_hyper(); eng.set_drop_path(drop.to(dev))
     eng.forward_backward(tiles.to(dev))
     torch.cuda.synchronize()
-    assert abs(float(eng.loss) - float(loss_r)) <= 2.5e-3, (float(eng.loss), float(loss_r))   # B = 2 (the B = 8 configs hold 1e-3)
+    assert abs(float(eng.loss) - float(loss_r)) <= 1e-3, (float(eng.loss), float(loss_r))
     assert float((eng.hb_s.logits.cpu() - s_out).abs().max()) <= 3e-2 * float(s_out.abs().max())
     _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))

@@ -235,6 +235,21 @@ def test_infer_tiles_chunks_and_labels(tmp_path):
     sl = D.scan_slides(str(tmp_path), "ER")
     assert [s[2] for s in sl] == [0, 1, 1] and [s[3] for s in sl] == ["1", "2", "1"]
     assert [s[0] for s in D.select_fold(sl, 1, train=True)] == ["s1"] and [s[0] for s in D.select_fold(sl, 1, train=False)] == ["s0", "s2"]
+    # the reference's fold rule (datasets.py:274-287): 'test' and 'val' slides are never trained on; evaluation = [test_fold, 'val'];
+    # test_fold -1 trains on every numbered fold; an empty selection raises instead of handing back all slides
+    mk = lambda folds: [(f"s{i}", [], 0, f) for i, f in enumerate(folds)]
+    sl5 = mk(["1", "2", "3", "test", "val", "1"])
+    names = lambda xs: [x[0] for x in xs]
+    assert names(D.select_fold(sl5, 1, True)) == ["s1", "s2"] and names(D.select_fold(sl5, 1, False)) == ["s0", "s4", "s5"]
+    assert names(D.select_fold(sl5, -1, True)) == ["s0", "s1", "s2", "s5"] and names(D.select_fold(sl5, 0, False)) == ["s3", "s4"]
+    assert names(D.select_fold(sl5, 0, True)) == ["s0", "s1", "s2", "s5"]
+    with pytest.raises(ValueError):
+        D.select_fold(mk(["1", "1"]), -1, False)            # the reference evaluates on nothing for -1
+    with pytest.raises(ValueError):
+        D.select_fold(mk(["test", "val"]), 2, True)
+    with pytest.raises(ValueError):
+        D.select_fold(mk(["1", "2"]), 3, False)
+    assert names(D.select_fold(mk([None, None]), 1, True)) == ["s0", "s1"] == names(D.select_fold(mk([None, None]), 1, False))
     syn = D.SyntheticSlides(n_slides=3, tiles_per_slide=5, tile_size=32, tiles_per_iter=2)
     chunks = list(syn)
     assert len(chunks) == len(syn) == 9 and sum(c["Is Last Batch"] for c in chunks) == 3 and chunks[2]["Data"].shape == (1, 32, 32, 3)
@@ -264,12 +279,34 @@ def test_every_used_flag_is_read_by_the_driver():
             assert reads == 0, f"{e['flags']} is read by train.py but marked used=False"
     # values the build cannot honour are refused before any GPU work
     for bad in (["--drop", "0.1"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "agc"], ["--in-chans", "1"],
-                ["--input-size", "3", "224", "200"], ["--dino", "--supervised"], ["--amp", "--amp-dtype", "bfloat16", "--precision", "fp32"]):
+                ["--input-size", "3", "224", "200"], ["--dino", "--supervised"], ["--amp", "--amp-dtype", "bfloat16", "--precision", "fp32"],
+                ["--opt", "lamb"], ["--opt", "rmsprop"], ["--opt", "nadam"], ["--opt", "momentum"], ["--sched", "tanh"], ["--sched", "plateau"],
+                ["--sched", "multistep"], ["--sched", "poly"], ["--dino", "--opt", "sgd"], ["--dino", "--opt", "adam"], ["--clip-mode", "value"]):
         args, _ = train.parse_args(["--model", "vit_tiny"] + bad)
         with pytest.raises(SystemExit):
             train.check_supported(args, lambda m: None)
     args, _ = train.parse_args(["--model", "vit_tiny", "--input-size", "3", "64", "64", "--amp", "--amp-dtype", "bfloat16", "--drop-path", "0.1"])
     assert train.check_supported(args, lambda m: None) == 64
+    # every accepted VALUE of --opt / --sched selects its own arithmetic (nothing is mapped onto a neighbour): the optimizer modes are
+    # distinct kernel modes, the schedules distinct curves; --dino moves the default of --opt to the recipe's adamw
+    from gipvit import sched as S
+    for o in train.SUPPORTED_OPTS:
+        a, _ = train.parse_args(["--model", "vit_tiny", "--opt", o]); train.check_supported(a, lambda m: None)
+    from gipvit.engine import SupervisedEngine
+    import inspect
+    assert all(f'"{o}"' in inspect.getsource(SupervisedEngine.__init__) for o in train.SUPPORTED_OPTS)
+    curves = {sc: [S.LrSchedule(1.0, sc, epochs=10, warmup_epochs=0, decay_epochs=3).at(e) for e in range(10)] for sc in train.SUPPORTED_SCHEDS}
+    assert curves["cosine"] != curves["step"] and len(set(curves["step"])) == 4
+    with pytest.raises(ValueError):
+        S.LrSchedule(1.0, "tanh")
+    a, _ = train.parse_args(["--model", "vit_tiny", "--dino"])
+    assert a.opt == "adamw" and train.check_supported(a, lambda m: None) is None
+    a, _ = train.parse_args(["--model", "vit_tiny"])
+    assert a.opt == "sgd"
+    # --amp-dtype float16 is not silently bf16: it is announced (fp16 autocast + loss scaling is not built)
+    msgs = []
+    a, _ = train.parse_args(["--model", "vit_tiny", "--amp", "--amp-dtype", "float16"]); train.check_supported(a, msgs.append)
+    assert any("fp16" in m for m in msgs)
     # --drop-path draws (gipvit.droppath): block 0 never drops, factors are 0 or 1 / keep, expectation 1
     import numpy as np
     from gipvit.droppath import DropPathSampler
@@ -305,6 +342,20 @@ def test_bench_launcher_spawns_ranks_with_torchrun_env(tmp_path):
     assert len({e[0]["MASTER_PORT"] for e in envs}) == 1 and envs[1][1] == ["--gpus", "3", "--steps", "2"]
     rc, _ = bench.launch_children(3, ["--fail"], child=[sys.executable, str(stub)], timeout=60)
     assert rc == 3                                                       # a failing rank fails the launch
+    # a rank other than 0 dies at start-up while rank 0 sits in its rendezvous: the launcher must notice the dead child, kill the
+    # rest and return that rank's code at once (it used to block on rank 0's pipe until the backend's timeout)
+    hang = tmp_path / "hang.py"
+    hang.write_text("import os, sys, time\n"
+                    "if os.environ['RANK'] == '1':\n"
+                    "    sys.stderr.write('rank 1: no such device\\n'); sys.exit(7)\n"
+                    "time.sleep(600)\n")
+    import time
+    t0 = time.monotonic()
+    rc, out = bench.launch_children(3, [], child=[sys.executable, str(hang)], timeout=120)
+    assert rc == 7 and out == "" and time.monotonic() - t0 < 30, (rc, out, time.monotonic() - t0)
+    t0 = time.monotonic()                                                # nobody fails, nobody finishes: the bound ends the job
+    rc, _ = bench.launch_children(2, [], child=[sys.executable, "-c", "import time; time.sleep(600)"], timeout=2)
+    assert rc == 124 and time.monotonic() - t0 < 30
     # end to end through main(): bare `--gpus 2` in a process without WORLD_SIZE goes to the launcher, not to the GPU
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, "-c", "import sys; sys.argv = ['bench.py', '--gpus', '2', '--steps', '1']\n"

@@ -109,7 +109,8 @@ def test_linear_epilogues(dev):
     close(Cf, 0.25 * (A.float() @ B.float().t()), 1e-4, 1e-4, "alpha")
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 384, 128), (2500, 1152, 384), (4099, 1536, 384), (3000, 384, 1536), (47000, 768, 128), (33000, 384, 256)])
+@pytest.mark.parametrize("M,N,K", [(2048, 384, 128), (2500, 1152, 384), (4099, 1536, 384), (3000, 384, 1536), (47000, 768, 128), (33000, 384, 256),
+                                   (44160, 1536, 384), (44160, 1152, 384), (25216, 1536, 384), (9999, 3072, 768), (100000, 1152, 128)])
 def test_linear_wide_panel(dev, M, N, K):
     """gv_linear's wide bf16 products (M >= 2048, N % 384 == 0, K % 128 == 0, hot-path epilogues) run on the full-row kernel:
     exact on integer data (NT and NN forms, ragged last row panel), epilogues against fp32 torch, and identical to the

@@ -102,11 +102,21 @@ def build_parser():
 def parse_args(argv=None):
     cfg, p = build_parser()
     known, remaining = cfg.parse_known_args(argv)
+    from_file = {}
     if known.config:
         with open(known.config) as f:
-            p.set_defaults(**yaml.safe_load(f))
+            from_file = yaml.safe_load(f) or {}
+            p.set_defaults(**from_file)
     args = p.parse_args(remaining)
+    # --dino (this build's addition) changes the DEFAULT of --opt from the reference's 'sgd' to the recipe's 'adamw'; an --opt the
+    # user did pass is never replaced (check_supported refuses what the DINO step cannot honour)
+    if args.dino and "opt" not in from_file and not any(a == "--opt" or a.startswith("--opt=") for a in remaining):
+        args.opt = "adamw"
     return args, yaml.safe_dump(vars(args), default_flow_style=False)
+
+
+SUPPORTED_OPTS = ("sgd", "adam", "adamw")          # modes of gv_adamw_ema (sgd = momentum + nesterov, timm's default for 'sgd')
+SUPPORTED_SCHEDS = ("cosine", "step")               # gipvit/sched.py
 
 
 def check_supported(args, log=_logger.warning):
@@ -125,6 +135,15 @@ def check_supported(args, log=_logger.warning):
     if args.clip_mode != "norm":
         raise SystemExit(f"--clip-mode {args.clip_mode}: only global-norm clipping ('norm', the reference default, train.py:1072-1077) is fused "
                          "into the optimizer kernel")
+    if args.opt.lower() not in SUPPORTED_OPTS:
+        raise SystemExit(f"--opt {args.opt}: the fused optimizer kernel (csrc/optim.hip) implements {' / '.join(SUPPORTED_OPTS)}; timm's other "
+                         "create_optimizer_v2 choices (reference train.py:161, 583) are not built and nothing is substituted for them")
+    if args.dino and args.opt.lower() != "adamw":
+        raise SystemExit(f"--dino --opt {args.opt}: the DINO step is AdamW with the recipe's weight-decay schedule (paper; the frozen-last-layer and "
+                         "teacher-EMA ranges are fused into that pass); pass --opt adamw")
+    if args.sched.lower() not in SUPPORTED_SCHEDS:
+        raise SystemExit(f"--sched {args.sched}: this build steps the learning rate by {' / '.join(SUPPORTED_SCHEDS)} (+ linear warm-up); timm's other "
+                         "create_scheduler_v2 choices (reference train.py:180, 881-887) are not built and a constant rate is not substituted")
     if args.in_chans not in (None, 3):
         raise SystemExit(f"--in-chans {args.in_chans}: the patch-embedding kernel reads 3-channel NHWC uint8 tiles")
     img = None
@@ -271,7 +290,7 @@ def main(argv=None):
         nc = args.num_classes or 2
         eng = SupervisedEngine(arch=arch, img_size=img, num_classes=nc, batch=B, lr=lr, weight_decay=args.weight_decay, betas=betas, eps=eps,
                                smoothing=args.smoothing, clip_grad=args.clip_grad or 0.0, mean=mean, std=std, device=dev, reducer=reducer,
-                               opt=opt if opt in ("adam", "adamw", "sgd") else "adamw", momentum=args.momentum,
+                               opt=opt, momentum=args.momentum,
                                train_backbone=not args.no_grad, model_ema_decay=ema_decay, precision=args.precision)
         st = (M.load_encoder_checkpoint(args.initial_checkpoint, arch, img, nc) if args.initial_checkpoint
               else M.init_vit_state(arch, img, nc, seed=args.seed))
@@ -341,6 +360,8 @@ def main(argv=None):
             ex["dino_center"] = eng.center.detach().cpu()
         elif ema_decay is not None:
             ex["state_dict_ema"] = eng.state_dict(ema=True)     # timm CheckpointSaver key
+        if drop_sampler is not None:
+            ex["drop_path_rng"] = drop_sampler.state_dict()     # a resumed run continues the mask stream
         return ex
 
     # the step's critical path runs on a high-priority stream; the engine's side stream (teacher forward,
@@ -355,6 +376,8 @@ def main(argv=None):
     if args.drop_path:
         from gipvit.droppath import DropPathSampler
         drop_sampler = DropPathSampler(ARCHS[arch]["depth"], (eng.V * B) if args.dino else B, args.drop_path, args.seed + 17 * rank, dev)
+        if args.resume and isinstance(ck.get("drop_path_rng"), dict):
+            drop_sampler.load_state_dict(ck["drop_path_rng"])
     cur_lr = lr
     # ---- epoch loop (train.py:905-977) / step loop (988-1143)
     for epoch in range(start_epoch, args.epochs):
