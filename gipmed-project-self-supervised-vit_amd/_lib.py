@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgipvit_hip.so")
+# GIPVIT_LIB: a lab build to time against the product library (tools/lab.sh) -- lab runs never overwrite the product file
+LIB_PATH = os.environ.get("GIPVIT_LIB") or os.path.join(HERE, "libgipvit_hip.so")
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

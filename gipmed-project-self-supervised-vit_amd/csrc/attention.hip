@@ -212,12 +212,21 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64, FwdCfg<NKT>::QT == 1 ? 2 : 1)
 // ---------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------
-template <int NKT>
+// KT = 16-key tiles per wave.  KT = 2: 32 keys per wave, ~190 registers, 2 waves per SIMD.  KT = 1: 16 keys per wave, the same
+// chain on half the keys in < 128 registers, 4 waves per SIMD -- but every wave still reads all of Q and dO from LDS, so the
+// workgroup's LDS read traffic of phase A doubles (measured: the short crops gain 20 %, N = 197 gains nothing; see gv_attention_bwd).
+template <int NKT, int KT>
+struct BwdCfg {
+    static constexpr int NKB = NKT / KT;               // key blocks of 16 KT keys = waves per pair
+    static constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
+    static constexpr int NW = NKB * PAIRS;             // waves per workgroup
+};
+template <int NKT, int KT>
 // short sequences run two 4-wave workgroups per CU: the second launch-bounds argument keeps them within 256 registers
-__global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 2) void attn_bwd_kernel(gv_attention_bwd_args a, int n_pairs) {
-    constexpr int NKB = NKT / 2;                       // 32-key blocks = waves per pair
-    constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
-    constexpr int NW = NKB * PAIRS;                    // waves per workgroup
+__global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<NKT, KT>::NW > 8) ? 1 : 2)) void attn_bwd_kernel(gv_attention_bwd_args a, int n_pairs) {
+    constexpr int NKB = BwdCfg<NKT, KT>::NKB, PAIRS = BwdCfg<NKT, KT>::PAIRS, NW = BwdCfg<NKT, KT>::NW;
+    constexpr int KW = 16 * KT;                        // keys per wave
+    constexpr int NK32 = NKT / 2;                      // 32-key slices of the dQ reduction
     constexpr int NP = NKT * 16;
     constexpr int IMG = NP * 128;
     constexpr int QH = NKT >= 8 ? 2 : 1;               // 32-query halves per barrier pair (short sequences keep 1)
@@ -271,7 +280,7 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
         }
         lse_q = a.lse[((long)img * H + h) * N + dq_q];
     }
-    const int lp = wave / NKB, kb = wave % NKB;        // local pair, this wave's 32-key block
+    const int lp = wave / NKB, kb = wave % NKB;        // local pair, this wave's key block
     const int pair_raw = blockIdx.x * PAIRS + lp;
     const bool valid = pair_raw < n_pairs;
     const int pair = valid ? pair_raw : n_pairs - 1;
@@ -287,10 +296,10 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
 
     // this wave's V fragments come straight from global: issued before the staging wait so
     // their latency overlaps the LDS-DMA of Q, K, dO and the delta pass
-    bf16x8 kf[2][2], vf[2][2];
+    bf16x8 kf[KT][2], vf[KT][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const int key = kb * 32 + kt * 16 + li;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int key = kb * KW + kt * 16 + li;
         const int keyc = key < N ? key : N - 1;
         const bf16* vrow = qkv + ((long)img * N + keyc) * ld + 2 * H * 64 + h * 64;
 #pragma unroll
@@ -319,16 +328,16 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
 
     // this wave's K fragments (B operands: lane = key, 8 consecutive d)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const int key = kb * 32 + kt * 16 + li;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int key = kb * KW + kt * 16 + li;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = read_nat(Kimg, key, ks * 4 + g);
     }
-    f32x4 dv[4][2], dk[4][2];
+    f32x4 dv[4][KT], dk[4][KT];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < KT; ++kt) { dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // 64 queries per barrier pair: phase A runs twice (two 32-query halves, registers as for one) and
     // fills both halves of the dS^T image, phase B then has 16 dQ tiles to spread over the waves
@@ -338,26 +347,26 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
         for (int half = 0; half < QH; ++half) {
             const int qc = qc2 * QH + half;
             if (qc * 32 >= N) break;
-            // ---- phase A: S, dP for [32 q] x [this wave's 32 keys]
-            f32x4 s[2][2], dp[2][2];
+            // ---- phase A: S, dP for [32 q] x [this wave's keys]
+            f32x4 s[2][KT], dp[2][KT];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int qrow = qc * 32 + qt * 16 + li;
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) { s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int kt = 0; kt < KT; ++kt) { s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 qa = read_nat(Qimg, qrow, ks * 4 + g);
                     const bf16x8 da = read_nat(Dimg, qrow, ks * 4 + g);
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
+                    for (int kt = 0; kt < KT; ++kt) {
                         s[qt][kt] = MFMA16(qa, kf[kt][ks], s[qt][kt]);
                         dp[qt][kt] = MFMA16(da, vf[kt][ks], dp[qt][kt]);
                     }
                 }
             }
             // P = exp(scale*S - lse[q]); dS = P * (dP - delta[q]) * scale.  rows q = 4g + r, col key = li
-            f32x4 pv[2][2], ds[2][2];
+            f32x4 pv[2][KT], ds[2][KT];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int q0 = qc * 32 + qt * 16 + 4 * g;
@@ -366,8 +375,8 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
                 l4 *= -1.4426950408889634f;
                 d4 *= -a.scale;
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    const bool kok = kb * 32 + kt * 16 + li < N;
+                for (int kt = 0; kt < KT; ++kt) {
+                    const bool kok = kb * KW + kt * 16 + li < N;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool ok = kok && (q0 + r < N);
@@ -379,16 +388,16 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
             }
             // dV^T += dO^T P ; dK^T += Q^T dS   (reduction over the chunk's 32 queries)
             {
-                bf16x8 pb[2], sb[2];
+                bf16x8 pb[KT], sb[KT];
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) { pb[kt] = pack8(pv[0][kt], pv[1][kt]); sb[kt] = pack8(ds[0][kt], ds[1][kt]); }
+                for (int kt = 0; kt < KT; ++kt) { pb[kt] = pack8(pv[0][kt], pv[1][kt]); sb[kt] = pack8(ds[0][kt], ds[1][kt]); }
                 const int r0 = qc * 32 + 4 * g + q4;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const bf16x8 dot = cat8(read_tr(Dimg, r0, dt, p4), read_tr(Dimg, r0 + 16, dt, p4));
                     const bf16x8 qtt = cat8(read_tr(Qimg, r0, dt, p4), read_tr(Qimg, r0 + 16, dt, p4));
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
+                    for (int kt = 0; kt < KT; ++kt) {
                         dv[dt][kt] = MFMA16(dot, pb[kt], dv[dt][kt]);
                         dk[dt][kt] = MFMA16(qtt, sb[kt], dk[dt][kt]);
                     }
@@ -396,8 +405,8 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
             }
             // dS^T image [key][32 QH q]: 32-B piece index XOR f(key) (conflict-free transposed reads)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int key = kb * 32 + kt * 16 + li;
+            for (int kt = 0; kt < KT; ++kt) {
+                const int key = kb * KW + kt * 16 + li;
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     *(GV_LDS bf16x4*)(dsT + key * DROW + (((half * 2 + qt) ^ (QH == 2 ? (key >> 1) & 3 : (key >> 2) & 1)) << 5) + g * 8) =
@@ -411,7 +420,7 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
             if (qc2 * 32 * QH + qt * 16 >= N) continue;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < NKB; ++ks) {
+            for (int ks = 0; ks < NK32; ++ks) {
                 // k-slot (g, j): key = 32 ks + 16 (j >> 2) + 4 g + (j & 3)
                 const int k0 = ks * 32 + 4 * g + q4;
                 const bf16x8 ka = cat8(read_tr(Kimg, k0, dt, p4), read_tr(Kimg, k0 + 16, dt, p4));
@@ -430,8 +439,8 @@ __global__ __launch_bounds__((NKT / 2 >= 4 ? NKT / 2 : 4) * 64, NKT >= 14 ? 1 : 
     // ---- dK, dV: lane = key, rows d = 16 dt + 4 g + r
     if (valid) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int key = kb * 32 + kt * 16 + li;
+        for (int kt = 0; kt < KT; ++kt) {
+            const int key = kb * KW + kt * 16 + li;
             if (key < N) {
                 bf16* dst = (bf16*)a.dqkv + ((long)img * N + key) * ld + h * 64 + 4 * g;
 #pragma unroll
@@ -456,10 +465,12 @@ template <int NKT> int launch_fwd(const gv_attention_fwd_args* a, hipStream_t s)
     return GV_OK;
 }
 
-template <int NKT> int launch_bwd(const gv_attention_bwd_args* a, hipStream_t s) {
-    constexpr int NKB = NKT / 2, PAIRS = NKB >= 4 ? 1 : 4 / NKB, NW = NKB * PAIRS, NP = NKT * 16;
+template <int NKT, int KT> int launch_bwd(const gv_attention_bwd_args* a, hipStream_t s) {
+    using B = BwdCfg<NKT, KT>;
+    constexpr int PAIRS = B::PAIRS, NW = B::NW, NP = NKT * 16;
     constexpr int LDS = PAIRS * (3 * NP * 128 + NP * (NKT >= 8 ? 128 : 64) + 2 * NP * 4);
-    auto kern = attn_bwd_kernel<NKT>;
+    static_assert(NW * 64 <= 1024, "workgroup size");
+    auto kern = attn_bwd_kernel<NKT, KT>;
     static GvLdsOptIn opt_in;
     if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, LDS, "gv_attention_bwd")) return rc;
     const int n_pairs = a->n_img * a->H;
@@ -488,9 +499,12 @@ extern "C" int gv_attention_bwd(const gv_attention_bwd_args* a, void* stream) {
     GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16) && gv_aligned(a->d_o, 16) && gv_aligned(a->dqkv, 16), GV_E_ALIGN,
                "gv_attention_bwd: buffers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (a->N <= 32) return launch_bwd<2>(a, s);
-    if (a->N <= 64) return launch_bwd<4>(a, s);
-    if (a->N <= 128) return launch_bwd<8>(a, s);
-    if (a->N <= 224) return launch_bwd<14>(a, s);
-    return launch_bwd<18>(a, s);
+    // keys per wave: 16 for the short crops (N = 37: 39.2 -> 31.4 us per launch of 512 images x 6 heads), 32 from N = 65 on (N = 197:
+    // 72.6 us against 73.8 with 16 -- twice the waves buy nothing there: per (image, head) pair the kernel is the SUM of ~8 us of
+    // exp / dS arithmetic, ~4 us of MFMA and ~8 us (32 keys) or ~12 us (16 keys) of LDS reads, phase-aligned by its barriers)
+    if (a->N <= 32) return launch_bwd<2, 2>(a, s);
+    if (a->N <= 64) return launch_bwd<4, 1>(a, s);
+    if (a->N <= 128) return launch_bwd<8, 2>(a, s);
+    if (a->N <= 224) return launch_bwd<14, 2>(a, s);
+    return launch_bwd<18, 2>(a, s);
 }

@@ -86,7 +86,23 @@ struct PanelP {
     const float* row_scale; const float* gb_scale;
     // wide (plain Linear with N = ncb x 384 output columns, bf16 out): out = epilogue(A W^T) one 384-column block after the other
     bf16* outb; long ldob; const bf16* aux_in; bf16* aux_out; long ld_aux; int ncb, n_total;
+#ifdef GV_PANEL_STAMPS          // lab: s_memtime stamps [workgroup][wave][panel][8]
+    unsigned long long* dbg;
+#endif
 };
+
+#ifdef GV_PANEL_STAMPS
+__device__ __forceinline__ unsigned long long panel_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PSTAMP(k) do { if (lane == 0 && blockIdx.x < 256 && it < 8) p.dbg[((blockIdx.x * 8 + wave) * 8 + it) * 8 + (k)] = panel_stamp(); } while (0)
+#else
+#define PSTAMP(k)
+#endif
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_WIDE = 2 };
 // MODE_WIDE epilogues (the GV_EPI_* combinations of the hot path's wide products)
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         for (int e = 0; e < 2; ++e) { s_dg[c][e] = 0.f; s_db[c][e] = 0.f; s_g[c][e] = 0.f; }
     for (int it = 0; it < nit; ++it) {
     int m0_next = m0;
+    PSTAMP(0);
     if constexpr (PP) {
         const bool has_next = MODE == MODE_WIDE && it + 1 < nit;
         uc_past = has_next ? 0 : nt - 1;
@@ -238,6 +255,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         // prologue: tile 0 is out (start of the kernel / before the previous block's epilogue); A, W0, W1 of tile 1 follow
         static_for<0, PA + 4>([&](auto X) { issue_x(X, 1, 1, baseA); });
         wait_vmcnt<PN_T + 2>();                               // A and W0 of tile 0 landed
+        PSTAMP(1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();            // the second half runs one barrier late
@@ -307,7 +325,11 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
             phase(I0{}, I1{}, t + 1); phase(I1{}, I1{}, t + 1); phase(I2{}, I1{}, t + 1);
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();            // pair the late half's last barrier
-        wait_vmcnt<0>();
+        // FWD / BWD: the epilogue's image overlays the whole ring, so the stream's never-consumed last pieces must have landed.
+        // WIDE: the image lives in stage 1 and behind it and the pieces in flight are the NEXT panel's tile 0 into stage 0 --
+        // they keep flying through the epilogue (the kernel's end waits for the last ones)
+        if constexpr (MODE != MODE_WIDE) wait_vmcnt<0>();
+        PSTAMP(2);
     }
     if constexpr (!PP) {
 #pragma unroll
@@ -336,7 +358,106 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                 for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
         }
     }
-    // ---- epilogue.  The accumulators pass through an LDS image so that the row phase works on whole rows, ONE WAVE PER
+    // ---- MODE_WIDE epilogue: PER WAVE, no workgroup barrier between its two ends.  A wave owns, of every 16-row fragment of
+    // its half, the columns 128 b + 32 wn + [0, 32) of the three weight blocks b: it transposes one fragment row at a time
+    // through a PRIVATE LDS image ([16 rows][3 x 32 columns] f32, stride 100 floats: b128 writes and b64 reads conflict-free)
+    // and works on units of 4 rows x 32 columns (lane: row 4 q + (lane >> 4), columns 2 (lane & 15) + {0, 1}): every global access
+    // of a unit is four 64-B row pieces (128-B for the f32 output), which the neighbouring wave (wn + 1) completes to full lines.
+    // Round 2 ran the wide epilogues on the LayerNorm kernels' scheme -- a workgroup-wide image, one wave per 768-B row, two
+    // barriers per 32 rows: 8 us per 176 x 384 panel with NO global store in it (tools/lab.sh GV_LAB_WIDE_NOSTORE), as long as
+    // the panel's k-loop.  Nothing here needs a whole row in one wave, so nothing needs the other waves.
+    if constexpr (MODE == MODE_WIDE) {
+        constexpr int RS = 100;
+        static_assert(C::STAGE + NW * 16 * RS * 4 <= C::LDS_WIDE, "per-wave images must fit behind ring stage 0");
+        constexpr bool WB = (EP >= EP_BIAS && EP <= EP_BIAS_GELU_SAVE) || EP == EP_BIAS_RESID;
+        // (lane-derived addresses are recomputed per panel from an opaque copy of the lane id: hoisted out of the panel loop they
+        //  would be held in registers across the k-loop, which has none to spare -- spills whose reloads drain the DMA stream)
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int urow = le >> 4, ucol = (le & 15) * 2, li16e = le & 15, gqe = le >> 4;
+        GV_LDS float* wimg = (GV_LDS float*)(smem + C::STAGE) + wave * (16 * RS);
+        f32x4 bw[3][2];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bw[b][j] = (WB && p.bias) ? *(const f32x4*)(p.bias + cb * PN + 128 * b + 16 * (2 * wn + j) + gqe * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        PSTAMP(3);
+        __syncthreads();                                          // every wave is past ring stage 1: it is image space now
+        PSTAMP(4);
+        static_for<0, FMH>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+#ifdef GV_LAB_WIDE_NOEPI        // lab: the k-loops alone (one accumulator value keeps them alive)
+            if (acc8[0][i][0][0] == 1.2345e38f) p.outb[0] = (bf16)1.0f;
+            if (true) return;
+#endif
+            if (i < nfr) {                                        // (wave-uniform; static but for a half's last fragment)
+                const int mrow = m0 + 16 * (f0 + i) + urow;       // + 4 q: this lane's row of unit (b, q); < M (every panel holds BM rows)
+                const int ccol = cb * PN + 32 * wn + ucol;        // + 128 b
+                bf16x2 ax[EP == EP_DGELU ? 12 : 1];
+                f32x2 ar[EP == EP_BIAS_RESID ? 12 : 1];
+                float rsc[EP == EP_BIAS_RESID ? 4 : 1];
+                if constexpr (EP == EP_DGELU || EP == EP_BIAS_RESID) {        // the fragment's global operand rows, all requested up front
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if constexpr (EP == EP_DGELU) ax[b * 4 + q] = *(const bf16x2*)(p.aux_in + (long)(mrow + 4 * q) * p.ld_aux + ccol + 128 * b);
+                            else ar[b * 4 + q] = *(const f32x2*)(p.resid + (long)(mrow + 4 * q) * p.ldr + ccol + 128 * b);
+                        }
+                    if constexpr (EP == EP_BIAS_RESID) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rsc[q] = p.row_scale ? p.row_scale[mrow + 4 * q] : 1.0f;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 v = acc8[b][i][j];
+                        if constexpr (WB) v += bw[b][j];
+                        *(GV_LDS f32x4*)(wimg + li16e * RS + 32 * b + 16 * j + gqe * 4) = v;
+                    }
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 t2 = *(GV_LDS f32x2*)(wimg + (4 * q + urow) * RS + 32 * b + ucol);       // (a wave's LDS accesses execute in order)
+                        float v0 = t2[0], v1 = t2[1];
+                        const long m = mrow + 4 * q;
+                        const int col = ccol + 128 * b;
+#ifdef GV_LAB_WIDE_NOSTORE      // lab: image transit + epilogue arithmetic, no global stores
+                        if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v0 = gelu_f(v0); v1 = gelu_f(v1); }
+                        if constexpr (EP == EP_DGELU) { v0 *= dgelu_f((float)ax[b * 4 + q][0]); v1 *= dgelu_f((float)ax[b * 4 + q][1]); }
+                        if (v0 + v1 == 1.2345e38f) p.outb[0] = (bf16)v0;
+                        if (true) continue;
+#endif
+                        if constexpr (EP == EP_BIAS_RESID) {
+                            *(f32x2*)(p.out + m * p.ldo + col) = f32x2{fmaf(v0, rsc[q], ar[b * 4 + q][0]), fmaf(v1, rsc[q], ar[b * 4 + q][1])};
+                        } else {
+                            if constexpr (EP == EP_BIAS_GELU_SAVE) {
+                                // nontemporal: the saved pre-activation is not read again before the backward pass; kept out of the
+                                // caches, more of h (the next kernel's A operand, written beside it) is still in L2 / Infinity Cache
+                                // when fc2 reads it (round 2: fc2 + LayerNorm forward 99 -> 89 us)
+                                __builtin_nontemporal_store(bf16x2{(bf16)v0, (bf16)v1}, (bf16x2*)(p.aux_out + m * p.ld_aux + col));
+                            }
+                            if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v0 = gelu_f(v0); v1 = gelu_f(v1); }
+                            if constexpr (EP == EP_DGELU) { v0 *= dgelu_f((float)ax[b * 4 + q][0]); v1 *= dgelu_f((float)ax[b * 4 + q][1]); }
+                            bf16x2* dst = (bf16x2*)(p.outb + m * p.ldob + col);
+#ifdef GV_LAB_WIDE_NT
+                            __builtin_nontemporal_store(bf16x2{(bf16)v0, (bf16)v1}, dst);
+#else
+                            *dst = bf16x2{(bf16)v0, (bf16)v1};
+#endif
+                        }
+                    }
+            }
+        });
+        PSTAMP(5);
+        __syncthreads();                                          // images are read: stage 1 may receive the next panel's tile 1
+        PSTAMP(6);
+    }
+    // ---- epilogue (FWD / BWD).  The accumulators pass through an LDS image so that the row phase works on whole rows, ONE WAVE PER
     // ROW (wave w: rows w, w + 8, .. of the pass): every global access is a full 512-B row segment and the row reductions
     // of the LayerNorm stay inside a wave.  The global rows a pass needs (forward: the residual; backward: x and g, mean,
     // rstd) are all requested BEFORE the pass's image barrier, so their HBM latency overlaps the image traffic and the
@@ -385,6 +506,8 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         const int slot = rr >> 1, h = slot / IBH, ii = slot % IBH;
         return 16 * (h * FMH + i0 + ii) + 8 * (rr & 1);
     };
+    if constexpr (MODE != MODE_WIDE) { PSTAMP(3); }
+    if constexpr (MODE != MODE_WIDE)
 #pragma unroll
     for (int i0 = 0; i0 < (PP ? FMH : FM); i0 += (PP ? IBH : IB)) {
         const int ni = PP ? ((FMH - i0) < IBH ? (FMH - i0) : IBH) : ((FM - i0) < IB ? (FM - i0) : IB);          // compile-time after unrolling
@@ -565,10 +688,12 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         }
         __syncthreads();                                          // image free for the next pass / the reduction below
     }
+    if constexpr (MODE != MODE_WIDE) { PSTAMP(6); }
     if constexpr (MODE == MODE_WIDE) {                            // next row panel (its tile 0 went out as tile nt of this panel's stream)
         m0 = m0_next; baseA = baseA_past;
     }
     }   // row panels (MODE_WIDE)
+    if constexpr (MODE == MODE_WIDE) wait_vmcnt<0>();             // the stream's last, never-consumed pieces land before the LDS is released
 
     if constexpr (MODE == MODE_BWD) {
         // column sums over this workgroup's rows -> partials[blockIdx][3][384] (gv_ln_finalize folds them)
@@ -603,6 +728,9 @@ int pick_fm(int M) {
     return 12;
 }
 
+#ifdef GV_PANEL_STAMPS
+unsigned long long* g_panel_dbg = nullptr;
+#endif
 // MODE_WIDE launch geometry (see the kernel's id mapping): groups of ncb sibling workgroups, ceil(groups / 8) per XCD
 int wide_grid(int M, int BM, int ncb) {
     const int P = (M + BM - 1) / BM, groups = (P + ncb - 1) / ncb;
@@ -625,6 +753,11 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
     static const Name kn;                                           // as rocprofv3 prints it (initialised once, thread-safe)
     const char* kname = kn.s;
     const int grid = MODE == MODE_WIDE ? wide_grid(p.M, C::BM, p.ncb) : (p.M + C::BM - 1) / C::BM;
+#ifdef GV_PANEL_STAMPS
+    if (!g_panel_dbg) { (void)hipMalloc(&g_panel_dbg, 256 * 8 * 8 * 8 * 8); }
+    (void)hipMemsetAsync(g_panel_dbg, 0, 256 * 8 * 8 * 8 * 8, s);
+    const_cast<PanelP&>(p).dbg = g_panel_dbg;
+#endif
     // algorithmic bytes: forward  A row + f32 residual in + f32 row out + bf16 normalised row out + stats;
     // backward  dY row + f32 x row + f32 g in / out + bf16 g out; + the weight once
     // wide: A row + the bf16 output row (+ the saved / re-read pre-activation row)
@@ -694,6 +827,10 @@ int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
     }
     return -1;
 }
+
+#ifdef GV_PANEL_STAMPS   // tuning-lab build only (tools/panel_stamps.py)
+extern "C" int gv_panel_dbg_read(unsigned long long* host) { if (!g_panel_dbg) return -1; return (int)hipMemcpy(host, g_panel_dbg, 256 * 8 * 8 * 8 * 8, hipMemcpyDeviceToHost); }
+#endif
 
 extern "C" int gv_linear_ln_blocks(int32_t M) {
     if (M <= 0) return 0;

@@ -76,7 +76,7 @@ def dominant_kernel_roofline(step_fn, steps: int = 3, vit=None):
     --stats` reports, profiles/*_step_kernel_stats_exclusive.csv) -- the figure that says how good the kernel itself is."""
     rows = _timed_rows(step_fn, steps)
     d = rows[0]
-    exclusive = None
+    exclusive, table_alone = None, None
     if vit is not None and vit.side is not None:
         keep, vit.side = vit.side, None
         try:
@@ -86,9 +86,11 @@ def dominant_kernel_roofline(step_fn, steps: int = 3, vit=None):
         if d["kernel"] in alone:
             exclusive = _figures(alone[d["kernel"]], steps)
             exclusive["note"] = "same kernel with the side stream off: one kernel on the chip at a time"
+        table_alone = {k: round(r["seconds"] / r["launches"] * 1e6, 2) for k, r in alone.items()}
     table = [{"kernel": r["kernel"], "launches_per_step": round(r["launches"] / steps, 2), "avg_us": round(r["seconds"] / r["launches"] * 1e6, 2),
               "ms_per_step": round(r["seconds"] / steps * 1e3, 3), "tflops": round(r["flops"] / r["seconds"] / 1e12, 1),
-              "gbs": round(r["bytes"] / r["seconds"] / 1e9, 0)} for r in rows]
+              "gbs": round(r["bytes"] / r["seconds"] / 1e9, 0),
+              **({"avg_us_exclusive": table_alone.get(r["kernel"])} if table_alone is not None else {})} for r in rows]
     traffic, src = _traffic_for(d["kernel"])
     return {**_figures(d, steps), "configuration": "in_step (the timed configuration: side stream on)" if exclusive is not None else "in_step",
             "traffic": traffic, "traffic_source": src, "traffic_measured_in": "profiles",
