@@ -147,6 +147,8 @@ def main():
                     "config 5 is --arch vit_base --batch 64 --micro 8 = 512 tiles per GPU and step); a parity-case run, not the headline line")
     ap.add_argument("--random-crops", action="store_true", help="cut random-resized crops on the device every step (gv_crop_resize) instead of "
                     "the fixed parity windows of SURVEY 8(d); the default (and the quoted metric) uses the fixed windows")
+    ap.add_argument("--view-augment", action="store_true", help="with --random-crops: per-crop colour jitter / grayscale / blur / solarisation in the "
+                    "pass that cuts the crops (gv_crop_augment)")
     ap.add_argument("--precision", default="bf16", choices=("bf16", "fp32"), help="fp32: the verification mode (every operand f32, csrc/f32path.hip); "
                     "the headline number is the bf16 training path")
     ap.add_argument("--trace-loss", action="store_true", help="debug: synchronise and print the loss after every step")
@@ -201,7 +203,11 @@ def main():
     if args.random_crops:
         from gipvit.multicrop import MultiCropSampler
         sampler = MultiCropSampler(args.batch, 256, 2, n_local, seed=1234 + rank)
-        step0 = lambda: eng.step(tiles, boxes=sampler.sample(dev))
+        views = None
+        if args.view_augment:
+            from gipvit.multicrop import ViewAugmentSampler
+            views = ViewAugmentSampler(args.batch, 2, n_local, seed=77 + rank)
+        step0 = lambda: eng.step(tiles, boxes=sampler.sample(dev), views=views.sample(dev) if views is not None else None)
     elif args.micro > 1:
         step0 = lambda: eng.step_micro(micro_tiles)
     else:
@@ -258,7 +264,7 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic", "rccl_ranks": rccl_ranks,
             "config": {"workload": f"{args.arch}/16 DINO 2x224+{n_local}x96 crops of 256px NHWC u8 tiles, K=65536 ({args.config})",
                        "tiles_per_gpu": args.batch * args.micro, "micro_batches": args.micro, "global_tiles": args.batch * args.micro * world, "parallelism": f"dp{world}",
-                       "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops)},
+                       "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops), "view_augment": bool(args.view_augment and args.random_crops)},
             "tiles_per_s_per_gpu": round(tiles_s / world, 2),
             "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[(args.arch, args.config)] / 1e3
                                           / (MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_BF16_PEAK_TFLOPS), 4)

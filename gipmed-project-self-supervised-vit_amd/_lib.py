@@ -28,6 +28,12 @@ gv_augment_params = _struct("gv_augment_params", [
     ("n_color", i32), ("order", i32 * 4), ("bf", f32), ("cf", f32), ("sf", f32), ("hue", i32), ("blur", i32), ("kc", f32), ("ks", f32),
     ("sigma", f32), ("seed", C.c_uint32), ("d4", i32), ("zoom", i32), ("a0", i32), ("a2", i32), ("cut", i32 * 4)])
 gv_augment_args = _struct("gv_augment_args", [("tiles", vp), ("out", vp), ("params", vp), ("stats", vp), ("ztable", vp), ("n", i32), ("H", i32), ("W", i32)])
+gv_view_params = _struct("gv_view_params", [
+    ("n_color", i32), ("order", i32 * 4), ("bf", f32), ("cf", f32), ("sf", f32), ("hue", i32), ("gray", i32), ("blur", i32), ("kc", f32), ("ks", f32),
+    ("solar", i32)])
+gv_crop_augment_args = _struct("gv_crop_augment_args", [
+    ("tiles", vp), ("out", vp), ("boxes", vp), ("params", vp), ("stats", vp), ("n_crops", i32), ("n_tiles", i32), ("tile_h", i32), ("tile_w", i32),
+    ("out_size", i32)])
 gv_crop_resize_args = _struct("gv_crop_resize_args", [
     ("tiles", vp), ("out", vp), ("boxes", vp), ("n_crops", i32), ("n_tiles", i32), ("tile_h", i32), ("tile_w", i32), ("out_size", i32)])
 gv_layernorm_fwd_args = _struct("gv_layernorm_fwd_args", [
@@ -93,7 +99,7 @@ gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
 
 # entry point -> argument struct (every `int gv_*(const args*, void* stream)` of the header)
 ENTRY_POINTS = {
-    "gv_patchify": gv_patchify_args, "gv_crop_resize": gv_crop_resize_args, "gv_augment": gv_augment_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
+    "gv_patchify": gv_patchify_args, "gv_crop_resize": gv_crop_resize_args, "gv_crop_augment": gv_crop_augment_args, "gv_augment": gv_augment_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
     "gv_colsum_finalize": gv_colsum_finalize_args, "gv_ln_finalize": gv_ln_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
     "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args, "gv_expand_rows": gv_expand_rows_args, "gv_linear_dw_group": gv_linear_dw_group_args,
     "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_cls_rows": gv_cls_rows_args,

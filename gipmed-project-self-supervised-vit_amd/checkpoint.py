@@ -31,7 +31,8 @@ class CheckpointSaver:
         if metric is not None:
             p["metric"] = float(metric)
         for k, v in (extra or {}).items():       # e.g. 'state_dict_ema' (timm key: the EMA model / DINO teacher), 'dino_center'
-            p[k] = ({n: t.detach().cpu() for n, t in v.items()} if isinstance(v, dict) else (v.detach().cpu() if torch.is_tensor(v) else v))
+            cpu = lambda t: t.detach().cpu() if torch.is_tensor(t) else t          # (plain str / int entries, e.g. a sampler's stream position, pass through)
+            p[k] = {n: cpu(t) for n, t in v.items()} if isinstance(v, dict) else cpu(v)
         return p
 
     def save_checkpoint(self, epoch: int, state_dict: Dict[str, torch.Tensor], optimizer: Optional[dict] = None,

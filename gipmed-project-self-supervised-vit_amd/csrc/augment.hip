@@ -65,8 +65,10 @@ __device__ __forceinline__ Px hue_shift(const Px p, int shift) {
     return o;
 }
 
-// colour operations [first, last) of the tile's order; `mean` = the contrast operation's grey mean
-__device__ __forceinline__ Px colour(Px p, const gv_augment_params& q, int first, int last, int mean) {
+// colour operations [first, last) of the tile's (gv_augment_params) or view's (gv_view_params) order; `mean` = the contrast
+// operation's grey mean
+template <class Q>
+__device__ __forceinline__ Px colour(Px p, const Q& q, int first, int last, int mean) {
     for (int k = first; k < last; ++k) {
         const int op = q.order[k];
         if (op == 0) { p = Px{blend1(0.f, p.r, q.bf), blend1(0.f, p.g, q.bf), blend1(0.f, p.b, q.bf)}; }
@@ -165,7 +167,150 @@ __global__ __launch_bounds__(256) void augment_kernel(gv_augment_args a) {
     dst[0] = (uint8_t)p.r; dst[1] = (uint8_t)p.g; dst[2] = (uint8_t)p.b;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// gv_crop_augment: DINO views.  view[y, x] = solarise( blur3( gray( jitter( resized_crop[y, x] ) ) ) ), the resized crop taken
+// straight from the tile (gv_crop_resize's float32 bilinear arithmetic, byte for byte) -- it is never stored.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Box { const uint8_t* src; int y0, x0, h, w, flip, W, out; float sy, sx; };
+
+__device__ __forceinline__ Box load_box(const gv_crop_augment_args& a, int n) {
+    const int* bx = a.boxes + n * 6;
+    Box b;
+    b.src = a.tiles + (long)bx[0] * a.tile_h * a.tile_w * 3;
+    b.y0 = bx[1]; b.x0 = bx[2]; b.h = bx[3]; b.w = bx[4]; b.flip = bx[5]; b.W = a.tile_w; b.out = a.out_size;
+    b.sy = (float)b.h / (float)b.out; b.sx = (float)b.w / (float)b.out;
+    return b;
+}
+
+// pixel (oy, oxo) of the resized (and flipped) crop
+__device__ __forceinline__ Px resample(const Box& b, int oy, int oxo) {
+    float fy = b.sy * ((float)oy + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int iy0 = (int)fy, iy1 = iy0 + (iy0 < b.h - 1 ? 1 : 0);
+    const float ly = fy - (float)iy0, ly0 = 1.0f - ly;
+    const int ox = b.flip ? b.out - 1 - oxo : oxo;
+    float fx = b.sx * ((float)ox + 0.5f) - 0.5f;
+    fx = fx < 0.f ? 0.f : fx;
+    const int ix0 = (int)fx, ix1 = ix0 + (ix0 < b.w - 1 ? 1 : 0);
+    const float lx = fx - (float)ix0, lx0 = 1.0f - lx;
+    const uint8_t* r0 = b.src + ((long)(b.y0 + iy0) * b.W + b.x0) * 3;
+    const uint8_t* r1 = b.src + ((long)(b.y0 + iy1) * b.W + b.x0) * 3;
+    int c3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float top = lx0 * (float)r0[ix0 * 3 + c] + lx * (float)r0[ix1 * 3 + c];
+        const float bot = lx0 * (float)r1[ix0 * 3 + c] + lx * (float)r1[ix1 * 3 + c];
+        float v = __builtin_rintf(ly0 * top + ly * bot);
+        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+        c3[c] = (int)v;
+    }
+    return Px{c3[0], c3[1], c3[2]};
+}
+
+__device__ __forceinline__ Px jitter_gray(Px p, const gv_view_params& q, int mean) {
+    p = colour(p, q, 0, q.n_color, mean);
+    if (q.gray) { const int l = lum(p); p = Px{l, l, l}; }
+    return p;
+}
+
+// per-crop sum of "L" over the view as it is just before the contrast operation
+__global__ __launch_bounds__(256) void view_stats_kernel(gv_crop_augment_args a) {
+    const int n = blockIdx.y;
+    const gv_view_params q = a.params[n];
+    int kc = -1;
+    for (int k = 0; k < q.n_color; ++k) if (q.order[k] == 1) kc = k;
+    if (kc < 0) return;
+    const Box b = load_box(a, n);
+    const int npx = a.out_size * a.out_size;
+    unsigned long long s = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+        const int y = i / a.out_size, x = i - y * a.out_size;
+        s += (unsigned long long)lum(colour(resample(b, y, x), q, 0, kc, 0));
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ unsigned long long red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd((unsigned long long*)a.stats + n, red[0] + red[1] + red[2] + red[3]);
+}
+
+// One 256-thread block per 32 x 32 output region.  Phase 1: the resized crop's pixels of the region (+ a one-pixel halo when the
+// view is blurred) go through the colour chain ONCE each and are parked in LDS (packed rgb); phase 2: every thread finishes
+// 4 adjacent pixels of a row -- the 3x3 taps summed in the oracle's raster order, solarise -- and stores 12 bytes as three
+// dwords.  (Evaluating the chain per tap cost 9 evaluations per blurred pixel: +2.5 ms per B = 64 step.)
+constexpr int VT = 32;
+__global__ __launch_bounds__(256) void crop_augment_kernel(gv_crop_augment_args a) {
+    __shared__ uint32_t win[(VT + 2) * (VT + 2)];
+    const int out = a.out_size;
+    const int n = blockIdx.z, ty0 = blockIdx.y * VT, tx0 = blockIdx.x * VT;
+    const gv_view_params q = a.params[n];
+    const Box b = load_box(a, n);
+    const int mean = (int)((double)a.stats[n] / (double)(out * out) + 0.5);
+    const int halo = q.blur ? 1 : 0, side = VT + 2 * halo;
+#pragma unroll 1
+    for (int i = threadIdx.x; i < side * side; i += 256) {
+        const int wy = i / side, wx = i - wy * side;
+        int yy = ty0 + wy - halo, xx = tx0 + wx - halo;
+        yy = yy < 0 ? -yy : (yy >= out ? 2 * out - 2 - yy : yy);                   // reflect padding (positions past a ragged region's
+        xx = xx < 0 ? -xx : (xx >= out ? 2 * out - 2 - xx : xx);                   //  edge stay inside the crop: never stored)
+        yy = yy < 0 ? 0 : yy; xx = xx < 0 ? 0 : xx;
+        const Px c = jitter_gray(resample(b, yy, xx), q, mean);
+        win[i] = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
+    }
+    __syncthreads();
+    const int ry = threadIdx.x >> 3, rx = (threadIdx.x & 7) * 4;                  // this thread's row and first column inside the region
+    const int oy = ty0 + ry, ox = tx0 + rx;
+    if (oy >= out || ox >= out) return;
+    uint32_t pk[3] = {0u, 0u, 0u};
+    const float k1[3] = {q.ks, q.kc, q.ks};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c3[3];
+        if (q.blur) {
+            float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const uint32_t c = win[(ry + dy) * side + rx + i + dx];
+                    const float w = k1[dy] * k1[dx];
+                    acc[0] = acc[0] + w * (float)(c & 255u); acc[1] = acc[1] + w * (float)((c >> 8) & 255u); acc[2] = acc[2] + w * (float)((c >> 16) & 255u);
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) c3[c] = (int)fminf(fmaxf(rintf(acc[c]), 0.f), 255.f);
+        } else {
+            const uint32_t c = win[ry * side + rx + i];
+            c3[0] = (int)(c & 255u); c3[1] = (int)((c >> 8) & 255u); c3[2] = (int)((c >> 16) & 255u);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int v = (q.solar >= 0 && c3[c] >= q.solar) ? 255 - c3[c] : c3[c];
+            const int bb = i * 3 + c;
+            pk[bb >> 2] |= (uint32_t)v << (8 * (bb & 3));
+        }
+    }
+    uint32_t* dst = (uint32_t*)(a.out + ((long)n * out * out + (long)oy * out + ox) * 3);
+    dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2];
+}
+
 }  // namespace
+
+extern "C" int gv_crop_augment(const gv_crop_augment_args* a, void* stream) {
+    GV_REQUIRE(a && a->tiles && a->out && a->boxes && a->params && a->stats, GV_E_NULL, "gv_crop_augment: null pointer");
+    GV_REQUIRE(a->n_crops > 0 && a->n_tiles > 0 && a->tile_h > 0 && a->tile_w > 0, GV_E_SHAPE, "gv_crop_augment: bad shape");
+    GV_REQUIRE(a->out_size > 1 && a->out_size % 4 == 0, GV_E_SHAPE, "gv_crop_augment: out_size=%d must be a multiple of 4 (> 1)", a->out_size);
+    GV_REQUIRE(a->n_crops <= 65535, GV_E_SHAPE, "gv_crop_augment: at most 65535 crops per call (got %d)", a->n_crops);
+    GV_REQUIRE(gv_aligned(a->out, 4) && gv_aligned(a->boxes, 4) && gv_aligned(a->params, 4) && gv_aligned(a->stats, 8), GV_E_ALIGN,
+               "gv_crop_augment: out / boxes / params / stats misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(augment_zero_kernel, dim3((a->n_crops + 255) / 256), dim3(256), 0, s, (unsigned long long*)a->stats, a->n_crops);
+    hipLaunchKernelGGL(view_stats_kernel, dim3(8, a->n_crops), dim3(256), 0, s, *a);
+    GV_LAUNCH_CHECK("gv_crop_augment(stats)");
+    const int nt = (a->out_size + VT - 1) / VT;
+    hipLaunchKernelGGL(crop_augment_kernel, dim3(nt, nt, a->n_crops), dim3(256), 0, s, *a);
+    GV_LAUNCH_CHECK("gv_crop_augment");
+    return GV_OK;
+}
 
 extern "C" int gv_augment(const gv_augment_args* a, void* stream) {
     GV_REQUIRE(a && a->tiles && a->out && a->params && a->stats && a->ztable, GV_E_NULL, "gv_augment: null pointer");

@@ -639,7 +639,7 @@ class DinoEngine:
         self.D, self.K, self.G, self.V = D, out_dim, n_global, n_global + n_local
         self.mean, self.std = tuple(mean), tuple(std)
         self.gsize, self.lsize = gsize, lsize
-        self._gcrops = self._lcrops = None       # crop buffers of the random-resized-crop path (allocated on first use)
+        self._gcrops = self._lcrops = self._vstats = None       # crop buffers of the random-resized-crop path (allocated on first use)
         if windows is None:   # deterministic crop windows of SURVEY 8(d): (y0, x0)
             windows = [(16 * g, 16 * g) for g in range(n_global)] + [(20 * l, 160 - 20 * l) for l in range(n_local)]
         self.gwins, self.lwins = list(windows[:n_global]), list(windows[n_global:])
@@ -742,11 +742,13 @@ class DinoEngine:
         vals[L.HYP_STUDENT_TEMP] = self.ts
         ops.store_f32(self.hyper, vals)
 
-    def forward_backward(self, tiles_u8: torch.Tensor, micro: Tuple[int, int] = (0, 1), boxes=None, fill=None):
+    def forward_backward(self, tiles_u8: torch.Tensor, micro: Tuple[int, int] = (0, 1), boxes=None, fill=None, views=None):
         """teacher fwd (global crops) -> student fwd (all crops) -> loss -> backward.
         Leaves gradients in arena.g, loss in self.loss, center_sum.  ``micro = (j, n)``: this is
         micro-batch j of n (gradient accumulation): gradients, loss and centre sums add up over
-        the n calls and the data-parallel reduction is issued from the last one only."""
+        the n calls and the data-parallel reduction is issued from the last one only.
+        ``views``: (global, local) packed per-crop records of multicrop.ViewAugmentSampler.sample -- with ``boxes``, every crop
+        gets its own colour jitter / grayscale / blur / solarisation in the pass that cuts it (gv_crop_augment)."""
         B, G, V = self.B, self.G, self.V
         a = self.arena
         mj, mn = micro
@@ -756,6 +758,8 @@ class DinoEngine:
         t_src, t_win, s_src, s_win = tiles_u8, [self.gwins], tiles_u8, self.s_wins
         if boxes is not None and fill is not None:
             raise ValueError("fill boxes are tile coordinates: they cannot be combined with re-cut random crops (boxes)")
+        if views is not None and boxes is None:
+            raise ValueError("views (per-crop augmentation draws) need boxes: the views are produced by the pass that cuts the crops")
         if boxes is not None:
             # random-resized crops (multicrop.MultiCropSampler): cut on the device, then every crop is its own
             # "tile" with the single window (0, 0); rows stay crop-major like the fixed windows
@@ -764,11 +768,19 @@ class DinoEngine:
             if self._gcrops is None:
                 self._gcrops = _empty((self.G * B, self.gsize, self.gsize, 3), torch.uint8, self.dev)
                 self._lcrops = _empty(((self.V - self.G) * B, self.lsize, self.lsize, 3), torch.uint8, self.dev) if self.V > self.G else None
-            ops.crop_resize(tiles_u8, bg, self.gsize, out=self._gcrops)
+            if views is not None and self._vstats is None:
+                self._vstats = torch.zeros(max(self.G, self.V - self.G) * B, dtype=torch.int64, device=self.dev)
+            if views is None:
+                ops.crop_resize(tiles_u8, bg, self.gsize, out=self._gcrops)
+            else:
+                ops.crop_augment(tiles_u8, bg, views[0], self._vstats, self.gsize, out=self._gcrops)
             t_src, t_win = self._gcrops, [[(0, 0)]]
             s_src, s_win = [self._gcrops], [[(0, 0)]]
             if self.V > self.G:
-                ops.crop_resize(tiles_u8, bl, self.lsize, out=self._lcrops)
+                if views is None:
+                    ops.crop_resize(tiles_u8, bl, self.lsize, out=self._lcrops)
+                else:
+                    ops.crop_augment(tiles_u8, bl, views[1], self._vstats, self.lsize, out=self._lcrops)
                 s_src.append(self._lcrops); s_win.append([(0, 0)])
         # the teacher's forward shares nothing with the student's until the loss: it runs on the
         # side stream beside the student forward (fills the tail of each other's kernels)
@@ -870,13 +882,13 @@ class DinoEngine:
             self._n_micro = 1
         return self.loss
 
-    def step(self, tiles_u8: torch.Tensor, boxes=None, fill=None, **sched) -> torch.Tensor:
+    def step(self, tiles_u8: torch.Tensor, boxes=None, fill=None, views=None, **sched) -> torch.Tensor:
         """One full training step on [B, tile, tile, 3] uint8 NHWC tiles.  Returns the
         (device, un-synchronised) loss tensor.  ``boxes``: (global, local) int32 device tensors from
         multicrop.MultiCropSampler.sample -- random-resized crops instead of the fixed parity windows."""
         assert tiles_u8.shape == (self.B, self.tile, self.tile, 3) and tiles_u8.dtype == torch.uint8
         self.set_hyper(**sched)
-        self.forward_backward(tiles_u8, boxes=boxes, fill=fill)
+        self.forward_backward(tiles_u8, boxes=boxes, fill=fill, views=views)
         self.optimizer_step()
         return self.loss
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 6
+#define GV_ABI_VERSION 7
 enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
        GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
@@ -84,6 +84,34 @@ typedef struct {
     int32_t n_crops, n_tiles, tile_h, tile_w, out_size;
 } gv_crop_resize_args;
 int gv_crop_resize(const gv_crop_resize_args* a, void* stream);
+
+/* ---- DINO view augmentation fused behind the random-resized crop: ONE pass over the tiles writes every augmented view
+ * (DINO's DataAugmentationDINO -- absent from the reference; its pixel operations are the ones the reference applies to
+ * whole tiles on the CPU, transformations.py:140-147: torchvision ColorJitter on PIL images + GaussianBlur(3)).  Per crop,
+ * with that crop's own draws (made on the host):
+ *   random-resized crop + flip (exactly gv_crop_resize's arithmetic)  ->  ColorJitter ops in `order` (n_color = 0: the
+ *   RandomApply missed)  ->  RandomGrayscale (PIL "L", replicated)  ->  Gaussian blur 3x3 on the jittered view (float32,
+ *   reflect padding, round half to even)  ->  solarise (PIL ImageOps.solarize: v >= threshold -> 255 - v).
+ * ColorJitter's contrast blends with the mean grey of the VIEW as it is when the operation runs: a first kernel takes it
+ * per crop (`stats`, device uint64 [n_crops], scratch).  The resized crop itself never exists in HBM.                      */
+typedef struct {
+    int32_t n_color;             /* colour operations applied (0..4)                                            */
+    int32_t order[4];            /* 0 brightness, 1 contrast, 2 saturation, 3 hue, in application order          */
+    float bf, cf, sf;            /* ImageEnhance factors                                                        */
+    int32_t hue;                 /* added to the H byte (mod 256)                                               */
+    int32_t gray;                /* 1: grayscale view                                                           */
+    int32_t blur; float kc, ks;  /* 3x3 Gaussian: centre / side weight of the normalised 1-D kernel             */
+    int32_t solar;               /* solarise threshold (DINO: 128), < 0: off                                    */
+} gv_view_params;
+typedef struct {
+    const uint8_t* tiles;        /* [n_tiles, tile_h, tile_w, 3] u8 (NHWC)                                      */
+    uint8_t* out;                /* [n_crops, out_size, out_size, 3] u8                                         */
+    const int32_t* boxes;        /* device int32 [n_crops][6] = {tile, y0, x0, h, w, flip} (as gv_crop_resize)  */
+    const gv_view_params* params; /* device [n_crops]                                                           */
+    uint64_t* stats;
+    int32_t n_crops, n_tiles, tile_h, tile_w, out_size;
+} gv_crop_augment_args;
+int gv_crop_augment(const gv_crop_augment_args* a, void* stream);
 
 /* ---- tile augmentation on the device (replaces the CPU / PIL recipes of transformations.py:131-197 on tiles that are
  * already in HBM).  One parameter record per tile, drawn on the host; operations in reference order:

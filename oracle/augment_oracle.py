@@ -209,3 +209,35 @@ def augment_tile(img, p, ztable):
         y0, y1, x0, x1 = p["cut"]
         img[y0:y1, x0:x1] = 0
     return img
+
+
+# --------------------------------------------------------------------------- #
+# DINO view augmentation (gv_crop_augment): per crop, after the random-resized crop + flip --
+# ColorJitter ops in the drawn order -> grayscale (PIL "L", replicated) -> 3x3 Gaussian blur -> solarise (PIL ImageOps.solarize).
+# Pinned against PIL in tests/test_oracle.py (convert("L"), ImageOps.solarize; the colour ops and the blur as above).
+# --------------------------------------------------------------------------- #
+def solarize(img, threshold=128):
+    return np.where(img >= threshold, 255 - img.astype(np.int64), img).astype(np.uint8)
+
+
+def to_gray(img):
+    return np.repeat(_L(img)[..., None], 3, -1).astype(np.uint8)
+
+
+def view_augment(crop, p):
+    """crop u8 [S, S, 3]; p: dict(order, bf, cf, sf, hue, gray, blur=(kc, ks) | None, solar=threshold | -1)."""
+    img = crop
+    for op in p.get("order", ()):
+        img = color_op(img, op, p)
+    if p.get("gray"):
+        img = to_gray(img)
+    if p.get("blur"):
+        img = blur3(img, *p["blur"])
+    if p.get("solar", -1) >= 0:
+        img = solarize(img, p["solar"])
+    return img
+
+
+def crop_views(tiles, boxes, out, params):
+    crops = crop_resize(tiles, boxes, out)
+    return np.stack([view_augment(c, p) for c, p in zip(crops, params)])

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), f"{name} declared in gipvit.h but not exported"
     bound = set(_lib.ENTRY_POINTS) | set(_lib.PLAIN_SYMBOLS)
     assert declared == bound, (declared - bound, bound - declared)
-    assert _lib.lib.gv_version() == 6 and _lib.lib.gv_target() == b"gfx950"
+    assert _lib.lib.gv_version() == 7 and _lib.lib.gv_target() == b"gfx950"
 
 
 def test_struct_layout_matches_header():

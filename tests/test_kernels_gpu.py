@@ -586,6 +586,33 @@ def test_crop_resize(dev):
         ops().crop_resize(t_dev, b_dev, 98)
 
 
+@pytest.mark.parametrize("out", [96, 224])
+def test_crop_augment_byte_exact(dev, out):
+    """gv_crop_augment (DINO views: random-resized crop + flip, then each crop's own ColorJitter order / grayscale / 3x3 blur /
+    solarise, written once) against the PIL-pinned oracle on the same boxes and draws: identical bytes.  With every operation
+    off it reproduces gv_crop_resize."""
+    import numpy as np
+    from gipvit.multicrop import MultiCropSampler, ViewAugmentSampler
+    from oracle import augment_oracle as ao
+    rng = np.random.default_rng(11)
+    B = 6
+    tiles = rng.integers(0, 256, (B, 256, 256, 3), dtype=np.uint8)
+    tiles[1] = 200                                                   # a flat tile: grey colours, S = 0 in the hue path
+    bg, bl = MultiCropSampler(B, 256, 2, 3, seed=2).sample()
+    boxes = (bg if out == 224 else bl).numpy()
+    vs = ViewAugmentSampler(B, 2, 3, jitter_p=0.9, gray_p=0.3, blur_p=(1.0, 0.5, 0.5), solar_p=(0.3, 0.5, 0.3), seed=4)
+    rec = vs.sample_host()[0 if out == 224 else 1]
+    rec["n_color"][0] = 0; rec["gray"][0] = 0; rec["blur"][0] = 0; rec["solar"][0] = -1       # one crop with everything off
+    t_dev, b_dev = torch.from_numpy(tiles).to(dev), torch.from_numpy(boxes).to(dev)
+    stats = torch.zeros(len(boxes), dtype=torch.int64, device=dev)
+    got = ops().crop_augment(t_dev, b_dev, ViewAugmentSampler.pack(rec).to(dev), stats, out).cpu().numpy()
+    ref = ao.crop_views(tiles, boxes, out, ViewAugmentSampler.to_dicts(rec))
+    bad = [(i, int((got[i] != ref[i]).sum()), int(np.abs(got[i].astype(int) - ref[i].astype(int)).max())) for i in range(len(boxes)) if not np.array_equal(got[i], ref[i])]
+    assert not bad, (bad[:4], ViewAugmentSampler.to_dicts(rec)[bad[0][0]])
+    assert np.array_equal(got[0], ops().crop_resize(t_dev, b_dev[:1].contiguous(), out).cpu().numpy()[0])
+    assert any(r["gray"] for r in rec) and any(r["solar"] >= 0 for r in rec) and any(r["blur"] for r in rec) and any(r["n_color"] for r in rec)
+
+
 @pytest.mark.parametrize("recipe", ["flip", "rvf", "cbnfrsc", "pcbnfrs", "cbnfr", "bnfrsc", "frs", "aug_receptornet"])
 def test_augment_byte_exact(dev, recipe):
     """gv_augment against oracle/augment_oracle.py on the same draws: byte-identical tiles for every recipe of

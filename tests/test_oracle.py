@@ -265,6 +265,44 @@ def test_augment_oracle_colour_ops_match_pil():
         assert (d.max(-1) == 0).mean() > 0.99 and d.max() <= 6, ((d.max(-1) == 0).mean(), d.max())
 
 
+def test_view_augment_oracle_matches_pil_and_sampler_statistics():
+    """DINO view augmentation (oracle/augment_oracle.py view_augment, the checker of gv_crop_augment): grayscale == PIL
+    convert("L") replicated, solarise == PIL ImageOps.solarize, a whole chain (brightness -> contrast -> saturation ->
+    grayscale -> solarise) == the same chain run through PIL's own modules; the host sampler draws DINO's probabilities."""
+    from PIL import Image, ImageEnhance, ImageOps
+    from oracle import augment_oracle as ao
+    from gipvit.multicrop import ViewAugmentSampler
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (96, 96, 3), dtype=np.uint8)
+    im = Image.fromarray(img)
+    assert np.array_equal(ao.to_gray(img), np.asarray(im.convert("L").convert("RGB")))
+    for th in (128, 0, 255, 77):
+        assert np.array_equal(ao.solarize(img, th), np.asarray(ImageOps.solarize(im, th)))
+    p = dict(order=[0, 1, 2], bf=1.3, cf=0.7, sf=1.15, hue=0, gray=False, blur=None, solar=128)
+    ref = ImageEnhance.Color(ImageEnhance.Contrast(ImageEnhance.Brightness(im).enhance(1.3)).enhance(0.7)).enhance(1.15)
+    assert np.array_equal(ao.view_augment(img, p), np.asarray(ImageOps.solarize(ref, 128)))
+    p = dict(order=[2, 0], bf=0.8, sf=0.9, gray=True, blur=None, solar=-1)
+    ref = ImageEnhance.Brightness(ImageEnhance.Color(im).enhance(0.9)).enhance(0.8).convert("L").convert("RGB")
+    assert np.array_equal(ao.view_augment(img, p), np.asarray(ref))
+    # blur runs on the jittered / grey view, before the solarisation
+    p = dict(order=[], gray=True, blur=(0.6, 0.2), solar=100)
+    assert np.array_equal(ao.view_augment(img, p), ao.solarize(ao.blur3(ao.to_gray(img), 0.6, 0.2), 100))
+    # the sampler: DINO's probabilities per crop kind (jitter 0.8, grey 0.2, blur 1.0 / 0.1 / 0.5, solarise 0 / 0.2 / 0)
+    sp = ViewAugmentSampler(batch=4000, n_global=2, n_local=2, seed=1)
+    g, l = sp.sample_host()
+    g1, g2 = g[:4000], g[4000:]
+    assert abs((g["n_color"] == 4).mean() - 0.8) < 0.03 and abs(g["gray"].mean() - 0.2) < 0.03
+    assert g1["blur"].all() and abs(g2["blur"].mean() - 0.1) < 0.03 and abs(l["blur"].mean() - 0.5) < 0.03
+    assert (g1["solar"] == -1).all() and abs((g2["solar"] == 128).mean() - 0.2) < 0.03 and (l["solar"] == -1).all()
+    assert 0.6 <= g["bf"].min() and g["bf"].max() <= 1.4 and 0.8 <= g["sf"].min() and g["sf"].max() <= 1.2
+    assert np.allclose(g["kc"] + 2 * g["ks"], 1.0, atol=1e-6)
+    d = ViewAugmentSampler.to_dicts(g[:3])
+    assert set(d[0]) == {"order", "bf", "cf", "sf", "hue", "gray", "blur", "solar"}
+    import ctypes
+    from gipvit import _lib
+    assert ViewAugmentSampler.DT.itemsize == ctypes.sizeof(_lib.gv_view_params) == 56
+
+
 def test_augment_oracle_geometry_and_host_sampler():
     """NEAREST zoom == PIL's affine transform (torchvision RandomAffine(degrees=0, scale) on PIL images); the dihedral
     composition and the blur weights of the host sampler; recipes draw what the reference's Compose would."""

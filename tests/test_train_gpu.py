@@ -166,6 +166,25 @@ def test_train_dino_drop_path(dev, tmp_path):
     assert 5.0 < float(rows[0]["train_loss"]) < 8.0
 
 
+@pytest.mark.gpu
+def test_train_dino_view_augment(dev, tmp_path):
+    """--random-crops --view-augment through the driver: every crop is cut and augmented (colour jitter / grayscale / blur /
+    solarise with its own draws) in one device pass; the run trains, is reproducible from its seed and differs from the
+    geometry-only views.  --view-augment without --random-crops is refused."""
+    sys.path.insert(0, ROOT)
+    import train
+    base = ["--dino", "--model", "vit_tiny", "--dataset", "synthetic", "-b", "2", "--out-dim", "1024", "--batches-per-epoch", "3", "--lr", "1e-4",
+            "--epochs", "1", "--log-interval", "1", "--output", str(tmp_path), "--seed", "7", "--no-validate", "--random-crops"]
+    for name, extra in (("va_a", ["--view-augment"]), ("va_b", ["--view-augment"]), ("geo", [])):
+        assert train.main(base + ["--experiment", name] + extra) == 0
+    w = {n: torch.load(tmp_path / n / "last.pth.tar", weights_only=True)["state_dict"]["backbone.blocks.0.attn.qkv.weight"] for n in ("va_a", "va_b", "geo")}
+    assert _rel(w["va_a"], w["va_b"]) < 1e-4 and _rel(w["va_a"], w["geo"]) > 1e-5
+    rows = list(csv.DictReader(open(tmp_path / "va_a" / "summary.csv")))
+    assert 5.0 < float(rows[0]["train_loss"]) < 8.0
+    with pytest.raises(SystemExit):
+        train.main([a for a in base if a != "--random-crops"] + ["--view-augment", "--experiment", "bad"])
+
+
 def test_train_precision_fp32(dev, tmp_path):
     """--precision fp32 through the driver (the reference's arithmetic without --amp): training, the EMA copy and the
     per-epoch slide validation all run on the f32 kernels; the run stays close to the bf16 run of the same seed (same

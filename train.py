@@ -79,6 +79,12 @@ def build_parser():
     g.add_argument("--local-crop-size", type=int, default=96)
     g.add_argument("--random-crops", action="store_true", help="DINO: random-resized crops + flips cut on the device every step "
                    "(gv_crop_resize); default = the fixed parity windows")
+    g.add_argument("--view-augment", action="store_true", help="DINO, with --random-crops: each crop gets its own ColorJitter / grayscale / "
+                   "3x3 Gaussian blur / solarisation (DINO's DataAugmentationDINO) in the pass that cuts it (gv_crop_augment)")
+    g.add_argument("--color-jitter-p", type=float, default=0.8, help="--view-augment: probability of the ColorJitter(0.4, 0.4, 0.2, 0.1)")
+    g.add_argument("--gray-p", type=float, default=0.2, help="--view-augment: probability of a grayscale view")
+    g.add_argument("--blur-p", type=float, nargs=3, default=(1.0, 0.1, 0.5), help="--view-augment: blur probability of global crop 1 / 2 / the local crops")
+    g.add_argument("--solarize-p", type=float, default=0.2, help="--view-augment: solarisation probability of global crop 2")
     g.add_argument("--global-crops-scale", type=float, nargs=2, default=(0.4, 1.0))
     g.add_argument("--local-crops-scale", type=float, nargs=2, default=(0.05, 0.4))
     g.add_argument("--momentum-teacher", type=float, default=0.996)
@@ -161,6 +167,8 @@ def check_supported(args, log=_logger.warning):
             "--precision fp32 is given")
     if args.amp and args.precision == "fp32":
         raise SystemExit("--amp asks for mixed precision, --precision fp32 for f32 operands throughout: pick one")
+    if args.view_augment and not (args.dino and args.random_crops):
+        raise SystemExit("--view-augment augments the crops that --dino --random-crops cuts on the device: pass both")
     if args.supervised and args.dino:
         raise SystemExit("--supervised (fine-tune with labels, train.py:715-717) and --dino (self-supervised) exclude each other")
     return img
@@ -352,6 +360,11 @@ def main(argv=None):
         from gipvit.multicrop import MultiCropSampler
         sampler = MultiCropSampler(B, tile, 2, args.local_crops_number, tuple(args.global_crops_scale), tuple(args.local_crops_scale),
                                    seed=args.seed + rank)
+    view_sampler = None
+    if args.view_augment:
+        from gipvit.multicrop import ViewAugmentSampler
+        view_sampler = ViewAugmentSampler(B, 2, args.local_crops_number, jitter_p=args.color_jitter_p, gray_p=args.gray_p, blur_p=tuple(args.blur_p),
+                                          solar_p=(0.0, args.solarize_p, 0.0), seed=args.seed + 53 * rank + 5)
 
     def extra_state():
         ex = {}
@@ -401,7 +414,8 @@ def main(argv=None):
                 sch = dict(lr=cur_lr, wd=S.cosine_between(args.weight_decay, args.weight_decay_end, it, total_updates),
                            momentum_teacher=S.cosine_between(args.momentum_teacher, 1.0, it, total_updates),
                            teacher_temp=teacher_temp_at(args, epoch))
-                loss_t = eng.step(data, boxes=sampler.sample(dev) if sampler is not None else None, fill=fill if sampler is None else None, **sch)
+                loss_t = eng.step(data, boxes=sampler.sample(dev) if sampler is not None else None, fill=fill if sampler is None else None,
+                                  views=view_sampler.sample(dev) if view_sampler is not None else None, **sch)
             else:
                 loss_t = eng.step(data, target, lr=cur_lr, fill=fill)
                 probs.append(eng.prob[:, 1].clone() if eng.C > 1 else eng.prob[:, 0].clone()); targets.append(target.view(-1).clone())
