@@ -54,7 +54,73 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
     }
 }
 
+// LAMB, both phases (include/gipvit.h gv_lamb).  One workgroup per table entry: a slice of ONE tensor.
+__global__ __launch_bounds__(256) void lamb_kernel(gv_lamb_args a) {
+    const int tensor = a.blocks[blockIdx.x * 3], lo = a.blocks[blockIdx.x * 3 + 1], hi = a.blocks[blockIdx.x * 3 + 2];
+    float gscale = a.grad_scale;
+    {
+        float nrm = sqrtf(*a.gnorm_sq) * fabsf(a.grad_scale);
+        if (a.clip_norm > 0.f) { const float c = a.clip_norm / (nrm + 1e-6f); if (c < 1.0f) { gscale *= c; nrm *= c; } }
+        if (a.max_grad_norm > 0.f && nrm > a.max_grad_norm) gscale *= a.max_grad_norm / nrm;
+    }
+    const float inv_bc1 = 1.0f / a.bias_corr1, inv_sqrt_bc2 = 1.0f / sqrtf(a.bias_corr2);
+    float trust = 1.0f;
+    if (a.phase == 1 && a.weight_decay != 0.f) {
+        const float wn = sqrtf(a.stats[2 * tensor]), un = sqrtf(a.stats[2 * tensor + 1]);
+        trust = (wn > 0.f && un > 0.f) ? wn / un : 1.0f;
+    }
+    const float om = 1.0f - a.teacher_momentum;
+    float sp = 0.f, su = 0.f;
+    for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += 256) {
+        f32x4 p = ((f32x4*)a.p)[i], m = ((f32x4*)a.m)[i], v = ((f32x4*)a.v)[i];
+        if (a.phase == 0) {
+            const f32x4 g = ((const f32x4*)a.grad)[i] * gscale;
+            m = m * a.beta1 + g * (1.0f - a.beta1);
+            v = v * a.beta2 + g * g * (1.0f - a.beta2);
+            ((f32x4*)a.m)[i] = m; ((f32x4*)a.v)[i] = v;
+        }
+        f32x4 u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = (m[j] * inv_bc1) / (sqrtf(v[j]) * inv_sqrt_bc2 + a.eps) + a.weight_decay * p[j];
+        if (a.phase == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sp += p[j] * p[j]; su += u[j] * u[j]; }
+        } else {
+            p -= u * (a.lr * trust);
+            ((f32x4*)a.p)[i] = p;
+            if (a.p_bf16) ((bf16x4*)a.p_bf16)[i] = bf16x4{(bf16)p[0], (bf16)p[1], (bf16)p[2], (bf16)p[3]};
+            if (a.teacher) {
+                f32x4 t = ((f32x4*)a.teacher)[i] * a.teacher_momentum + p * om;
+                ((f32x4*)a.teacher)[i] = t;
+                if (a.teacher_bf16) ((bf16x4*)a.teacher_bf16)[i] = bf16x4{(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
+            }
+        }
+    }
+    if (a.phase == 0) {
+        sp = wave_sum(sp); su = wave_sum(su);
+        __shared__ float red[8];
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sp; red[4 + (threadIdx.x >> 6)] = su; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(a.stats + 2 * tensor, red[0] + red[1] + red[2] + red[3]);
+            atomicAdd(a.stats + 2 * tensor + 1, red[4] + red[5] + red[6] + red[7]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int gv_lamb(const gv_lamb_args* a, void* stream) {
+    GV_REQUIRE(a && a->p && a->grad && a->m && a->v && a->blocks && a->stats && a->gnorm_sq, GV_E_NULL, "gv_lamb: null pointer");
+    GV_REQUIRE(a->phase == 0 || a->phase == 1, GV_E_UNSUPPORTED, "gv_lamb: phase must be 0 (moments + norms) or 1 (apply)");
+    GV_REQUIRE(a->n_blocks > 0, GV_E_SHAPE, "gv_lamb: empty block table");
+    GV_REQUIRE(gv_aligned(a->p, 16) && gv_aligned(a->grad, 16) && gv_aligned(a->m, 16) && gv_aligned(a->v, 16), GV_E_ALIGN,
+               "gv_lamb: buffers must be 16-byte aligned");
+    GV_REQUIRE(a->bias_corr1 > 0.f && a->bias_corr2 > 0.f, GV_E_SHAPE, "gv_lamb: bias corrections must be > 0");
+    hipLaunchKernelGGL(lamb_kernel, dim3((unsigned)a->n_blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_lamb");
+    return GV_OK;
+}
 
 extern "C" int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream) {
     GV_REQUIRE(a && a->p && a->grad && a->m && a->v, GV_E_NULL, "gv_adamw_ema: null pointer");

@@ -934,11 +934,26 @@ class SupervisedEngine:
         self.lr, self.wd, self.betas, self.eps, self.smoothing, self.clip = lr, weight_decay, betas, eps, smoothing, clip_grad
         self.t = 0
         self.reducer = reducer if reducer is not None else NoReducer()
-        if opt not in ("adamw", "adam", "sgd"):
-            raise ValueError(f"--opt {opt}: this build fuses adamw / adam / sgd (nesterov) only")
-        self.opt_mode = {"adamw": 0, "adam": 1, "sgd": 2}[opt]
+        if opt not in ("adamw", "adam", "sgd", "lamb"):
+            raise ValueError(f"--opt {opt}: this build fuses adamw / adam / sgd (nesterov) / lamb only")
+        self.opt = opt
+        self.opt_mode = {"adamw": 0, "adam": 1, "sgd": 2, "lamb": -1}[opt]
         if opt == "sgd":
             self.betas = (momentum, betas[1])
+        if opt == "lamb":
+            # timm.optim.Lamb (reference train.py:161, 583): per-tensor trust ratio -> every tensor's norms are needed before its
+            # update: two launches per arena segment over a block table that never crosses a tensor (gv_lamb)
+            a = self.arena
+            self._lamb_names = list(a.order)
+            spans = [a.span(n) for n in self._lamb_names]
+            self._lamb_tab = ops.lamb_block_table(spans).to(dev)
+            self._lamb_decay = torch.tensor([0.0 if no_weight_decay(n, a.specs[n]) else 1.0 for n in self._lamb_names])
+            # decayed tensors open the arena (Arena layout): two sub-tables, one per weight-decay value
+            nd = sum(1 for n in self._lamb_names if not no_weight_decay(n, a.specs[n]))
+            tid = self._lamb_tab[:, 0]
+            self._lamb_tabs = (self._lamb_tab[tid < nd].contiguous(), self._lamb_tab[tid >= nd].contiguous())
+            self._lamb_stats = torch.zeros(2 * len(self._lamb_names), dtype=f32, device=dev)
+            self.lamb_max_grad_norm = 1.0          # timm Lamb default
         self.train_backbone = train_backbone      # False = --no-grad head-only fine-tune (train.py:497-503)
 
     def load_state(self, state: Dict[str, torch.Tensor], ema_state: Optional[Dict[str, torch.Tensor]] = None):
@@ -992,6 +1007,18 @@ class SupervisedEngine:
                   grad_scale=1.0 / self.reducer.world, clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None,
                   mode=self.opt_mode, teacher_momentum=self.ema_decay or 0.0)
         tt = (lambda sl: (a.t[sl], a.tb[sl])) if a.t is not None else (lambda sl: (None, None))
+        if self.opt_mode < 0:
+            if not self.train_backbone:
+                raise ValueError("--opt lamb with --no-grad (head-only fine-tune) is not built: use adamw / adam / sgd")
+            ops.sumsq(a.g, self.red_ws, self.gnorm_sq)              # Lamb clips by the global norm itself (max_grad_norm = 1)
+            self._lamb_stats.zero_()
+            kl = dict(lr=kw["lr"], beta1=kw["beta1"], beta2=kw["beta2"], eps=self.eps, step=self.t, grad_scale=kw["grad_scale"],
+                      clip_norm=self.clip, max_grad_norm=self.lamb_max_grad_norm, teacher_momentum=self.ema_decay or 0.0)
+            for phase in (0, 1):
+                for tab, wd in zip(self._lamb_tabs, (self.wd, 0.0)):
+                    if tab.shape[0]:
+                        ops.lamb(a.p, a.g, a.m, a.v, a.pb, a.t, a.tb, tab, self._lamb_stats, self.gnorm_sq, phase=phase, weight_decay=wd, **kl)
+            return
         if self.train_backbone:
             ranges = [(0, a.n_decay, self.wd), (a.n_decay, a.n, 0.0)]
         else:

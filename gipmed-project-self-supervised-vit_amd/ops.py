@@ -333,3 +333,24 @@ def adamw_ema(p, grad, m, v, p_bf16, teacher, teacher_bf16, n: int, *, lr, beta1
                             lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
                             grad_scale, clip_norm, _p(gnorm_sq), teacher_momentum, _p(hyper), mode)
     L.call("gv_adamw_ema", a, _stream())
+
+
+def lamb_block_table(tensors, chunk: int = 1 << 16) -> torch.Tensor:
+    """Block table of gv_lamb for tensors = [(lo, hi), ...] (element ranges of a flat buffer, multiples of 4, in tensor-id order):
+    int32 [n_blocks, 3] = (tensor, lo, hi), slices of at most ``chunk`` elements that never cross a tensor."""
+    rows = []
+    for t, (lo, hi) in enumerate(tensors):
+        assert lo % 4 == 0 and hi % 4 == 0 and hi > lo
+        for a in range(lo, hi, chunk):
+            rows.append((t, a, min(hi, a + chunk)))
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+def lamb(p, grad, m, v, p_bf16, teacher, teacher_bf16, blocks, stats, gnorm_sq, *, phase: int, lr, beta1, beta2, eps, weight_decay, step: int,
+         grad_scale=1.0, clip_norm=0.0, max_grad_norm=1.0, teacher_momentum=0.0):
+    """One phase of LAMB over the tensors of ``blocks`` (device int32 [n, 3], offsets relative to the buffers passed); see gv_lamb."""
+    assert blocks.dtype == torch.int32 and blocks.is_contiguous() and stats.dtype == f32
+    a = L.gv_lamb_args(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), _p(teacher), _p(teacher_bf16), blocks.data_ptr(),
+                       blocks.shape[0], stats.data_ptr(), lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
+                       grad_scale, clip_norm, max_grad_norm, gnorm_sq.data_ptr(), teacher_momentum, phase)
+    L.call("gv_lamb", a, _stream())

@@ -462,6 +462,28 @@ typedef struct {
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
 
+/* ---- LAMB (timm `--opt lamb`, reference train.py:161 -> create_optimizer_v2 -> timm.optim.Lamb; named in SURVEY 8f-4) over the
+ * same flat arena, two launches per range (a per-TENSOR trust ratio needs every tensor's norms before its update):
+ *   phase 0:  g = grad * grad_scale * c, c = the global-norm clips (clip_norm as in gv_adamw_ema, then Lamb's own
+ *             max_grad_norm: g /= max(||g|| / max_grad_norm, 1));  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+ *             u = (m / bias_corr1) / (sqrt(v) / sqrt(bias_corr2) + eps) + weight_decay * p;
+ *             stats[2 t] += ||p||^2, stats[2 t + 1] += ||u||^2 over tensor t  (the caller zeroes `stats` first)
+ *   phase 1:  p -= lr * r_t * u with r_t = ||p|| / ||u|| if weight_decay != 0 and both norms > 0, else 1 (timm:
+ *             always_adapt = False);  bf16 refresh + teacher / --model-ema EMA as in gv_adamw_ema.
+ * `blocks`: device int32 [n_blocks][3] = {tensor, lo, hi}: element range [lo, hi) of the arena range handled by one
+ * workgroup, never crossing a tensor (built once by the host from the arena layout; lo, hi multiples of 4).            */
+typedef struct {
+    float* p; const float* grad; float* m; float* v; void* p_bf16;
+    float* teacher; void* teacher_bf16;
+    const int32_t* blocks; int32_t n_blocks;
+    float* stats;                /* f32 [2 * n_tensors]                                                              */
+    float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2;
+    float grad_scale, clip_norm, max_grad_norm; const float* gnorm_sq;     /* gnorm_sq: sum of squares of the raw gradient */
+    float teacher_momentum;
+    int32_t phase;
+} gv_lamb_args;
+int gv_lamb(const gv_lamb_args* a, void* stream);
+
 /* ---- fp32 operand mode (SURVEY 8d fp32 column; the reference's default arithmetic, train.py without --amp) -------
  * The same entry points with EVERY bf16 buffer of the argument struct read / written as f32 instead (activations,
  * GEMM operands incl. the weights, aux_in / aux_out, attention q/k/v/o/dO/dqkv, LayerNorm y / dy / gb, patch rows);

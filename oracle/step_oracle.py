@@ -90,11 +90,11 @@ class SupervisedOracle:
     """BASELINE config 1: single crop, timm head, softmax -> LabelSmoothingCE."""
 
     def __init__(self, arch="vit_tiny", img_size=64, num_classes=2, seed=0, lr=1e-3, wd=0.0,
-                 smoothing=0.1, dtype=torch.float32):
+                 smoothing=0.1, dtype=torch.float32, opt="adamw"):
         self.arch, self.dtype, self.img = arch, dtype, img_size
         self.p = vo.init_vit(arch, img_size, num_classes, seed, dtype)
         self.smoothing = smoothing
-        self.opt = vo.AdamW(self.p, lr, wd)
+        self.opt = vo.Lamb(self.p, lr, wd) if opt == "lamb" else vo.AdamW(self.p, lr, wd)
 
     def forward_backward(self, tiles_u8, target, drop=None):
         x = vo.normalize_window(tiles_u8, (0, 0, self.img), dtype=self.dtype)

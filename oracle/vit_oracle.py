@@ -342,3 +342,37 @@ class AdamW:
             self.v[k].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
             denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps)
             p.addcdiv_(self.m[k], denom, value=-lr / bc1)
+
+
+class Lamb:
+    """timm.optim.Lamb restated (reference train.py:161 `--opt lamb` -> create_optimizer_v2; timm is not importable here, so this
+    follows the published algorithm -- parity unpinned beyond this restatement): global-norm pre-clip to max_grad_norm, Adam
+    moments with bias correction, update + wd * p, per-TENSOR trust ratio ||p|| / ||update|| where the tensor is decayed
+    (always_adapt=False), p -= lr * ratio * update.  Defaults: betas (0.9, 0.999), eps 1e-6, max_grad_norm 1."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], lr, wd, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0):
+        self.p, self.lr, self.wd, self.b1, self.b2, self.eps, self.mgn = params, lr, wd, betas[0], betas[1], eps, max_grad_norm
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, grads: Dict[str, torch.Tensor], lr: Optional[float] = None):
+        lr = self.lr if lr is None else lr
+        self.t += 1
+        bc1, bc2 = 1 - self.b1 ** self.t, 1 - self.b2 ** self.t
+        gn = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None))
+        clip = max(gn / self.mgn, 1.0) if self.mgn else 1.0
+        for k, p in self.p.items():
+            if grads.get(k) is None:
+                continue
+            g = grads[k] / clip
+            self.m[k].mul_(self.b1).add_(g, alpha=1 - self.b1)
+            self.v[k].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            upd = (self.m[k] / bc1) / ((self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps))
+            wd = 0.0 if no_weight_decay(k, p) else self.wd
+            if wd != 0:
+                upd = upd + wd * p
+                wn, un = float(p.norm()), float(upd.norm())
+                upd = upd * (wn / un if wn > 0 and un > 0 else 1.0)
+            p.add_(upd, alpha=-lr)

@@ -352,3 +352,25 @@ def test_fp32_feature_extractor_and_model_seam(dev):
     m.load_state_dict(p)
     out = m(tiles.to(dev))
     assert out.dtype == f32 and _rel(out, ref_l) < 1e-5
+
+
+@gpu
+def test_lamb_supervised_steps_match_oracle_fp32(dev):
+    """--opt lamb end to end (config 1's model, fp32 operand mode so that no bf16 noise sits between the two optimizers): five
+    steps of SupervisedEngine(opt="lamb") against the oracle's Lamb restatement -- losses within 1e-4, weights within 1e-4."""
+    from gipvit.engine import SupervisedEngine
+    from oracle import step_oracle as so, vit_oracle as vo
+    orc = so.SupervisedOracle(arch="vit_tiny", img_size=64, num_classes=2, seed=0, lr=5e-3, wd=0.05, opt="lamb")
+    eng = SupervisedEngine(arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=5e-3, weight_decay=0.05, eps=1e-6, opt="lamb", device=dev,
+                           precision="fp32")
+    eng.load_state(orc.p)
+    tiles = vo.synth_tiles(8, 64, seed=1234)
+    tgt = torch.randint(0, 2, (8, 1), generator=torch.Generator().manual_seed(5))
+    for i in range(5):
+        r = orc.step(tiles, tgt)
+        l = eng.step(tiles.to(dev), tgt.to(dev))
+        assert abs(float(l) - r["loss"]) <= 1e-4, (i, float(l), r["loss"])
+    sd = eng.state_dict()
+    for k in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "head.weight", "pos_embed", "blocks.3.norm1.weight"):
+        d = float((sd[k].cpu() - orc.p[k]).norm() / orc.p[k].norm())
+        assert d < 1e-4, (k, d)

@@ -565,6 +565,46 @@ def test_adamw_ema(dev):
         close(p3, pr.detach(), 1e-5, 1e-6, f"optimizer mode {mode}")
 
 
+def test_lamb_matches_oracle(dev):
+    """gv_lamb (timm --opt lamb: global-norm pre-clip, Adam moments, per-tensor trust ratio on the decayed tensors, EMA copy) against
+    the oracle's restatement over an arena of three tensors, three steps."""
+    import math
+    from oracle import vit_oracle as vo
+    g = torch.Generator().manual_seed(21)
+    shapes = {"blocks.0.mlp.fc1.weight": (96, 64), "blocks.0.attn.qkv.weight": (40, 64), "blocks.0.mlp.fc1.bias": (96,)}     # two decayed, one not
+    params = {k: torch.randn(*sh, generator=g) * 0.3 for k, sh in shapes.items()}
+    orc = vo.Lamb({k: v.clone() for k, v in params.items()}, lr=2e-3, wd=0.05)
+    spans, off = [], 0
+    for k, sh in shapes.items():
+        n = (math.prod(sh) + 63) // 64 * 64
+        spans.append((off, off + n)); off += n
+    flat = lambda d: torch.cat([torch.nn.functional.pad(d[k].reshape(-1), (0, (sp[1] - sp[0]) - d[k].numel())) for k, sp in zip(shapes, spans)])
+    P = flat(params).to(dev); M, V, T = torch.zeros_like(P), torch.zeros_like(P), P.clone()
+    Pb, Tb = torch.zeros(off, dtype=bf16, device=dev), torch.zeros(off, dtype=bf16, device=dev)
+    tab = ops().lamb_block_table(spans, chunk=2048).to(dev)
+    tabs = (tab[tab[:, 0] < 2].contiguous(), tab[tab[:, 0] >= 2].contiguous())
+    stats, gsq, ws = torch.zeros(6, device=dev), torch.zeros(1, device=dev), torch.empty(1024, device=dev)
+    t_ref = {k: v.clone() for k, v in params.items()}
+    for step in range(1, 4):
+        grads = {k: torch.randn(*sh, generator=g) * (3.0 if step == 1 else 0.05) for k, sh in shapes.items()}      # step 1 triggers the global clip
+        orc.step(grads)
+        for k in t_ref:
+            t_ref[k] = 0.99 * t_ref[k] + 0.01 * orc.p[k]
+        G = flat(grads).to(dev)
+        ops().sumsq(G, ws, gsq); stats.zero_()
+        for phase in (0, 1):
+            for tb, wd in zip(tabs, (0.05, 0.0)):
+                ops().lamb(P, G, M, V, Pb, T, Tb, tb, stats, gsq, phase=phase, lr=2e-3, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=wd, step=step,
+                           teacher_momentum=0.99)
+    torch.cuda.synchronize()
+    for (k, sh), (lo, hi) in zip(shapes.items(), spans):
+        n = math.prod(sh)
+        close(P[lo:lo + n].view(sh).cpu(), orc.p[k], 1e-5, 1e-6, f"lamb p {k}")
+        close(T[lo:lo + n].view(sh).cpu(), t_ref[k], 1e-5, 1e-6, f"lamb ema {k}")
+        close(Pb[lo:lo + n].view(sh).cpu(), orc.p[k], 1e-2, 1e-2, f"lamb bf16 {k}")
+        close(M[lo:lo + n].view(sh).cpu(), orc.m[k], 1e-5, 1e-7, f"lamb m {k}")
+
+
 def test_crop_resize(dev):
     """gv_crop_resize vs the CPU restatement: same float32 arithmetic in the same association -> identical bytes."""
     import numpy as np

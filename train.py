@@ -121,7 +121,7 @@ def parse_args(argv=None):
     return args, yaml.safe_dump(vars(args), default_flow_style=False)
 
 
-SUPPORTED_OPTS = ("sgd", "adam", "adamw")          # modes of gv_adamw_ema (sgd = momentum + nesterov, timm's default for 'sgd')
+SUPPORTED_OPTS = ("sgd", "adam", "adamw", "lamb")  # modes of gv_adamw_ema (sgd = momentum + nesterov, timm's default for 'sgd') + gv_lamb
 SUPPORTED_SCHEDS = ("cosine", "step")               # gipvit/sched.py
 
 
@@ -243,7 +243,7 @@ def main(argv=None):
     if primary:
         _logger.info(f"Learning rate ({lr}) calculated from base learning rate ({args.lr_base}) and global batch size ({B * world})")
     betas = tuple(args.opt_betas) if args.opt_betas else (0.9, 0.999)
-    eps = args.opt_eps if args.opt_eps is not None else 1e-8
+    eps = args.opt_eps if args.opt_eps is not None else (1e-6 if opt == "lamb" else 1e-8)       # timm defaults: Lamb 1e-6, Adam(W) 1e-8
 
     # ---- data (batch dict contract of the reference: 'Data', 'Target'; inference: Infer_Dataset's dict)
     synthetic = args.dataset in ("", "synthetic")
