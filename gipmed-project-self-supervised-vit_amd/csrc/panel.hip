@@ -394,6 +394,14 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
             if (i < nfr) {                                        // (wave-uniform; static but for a half's last fragment)
                 const int mrow = m0 + 16 * (f0 + i) + urow;       // + 4 q: this lane's row of unit (b, q); < M (every panel holds BM rows)
                 const int ccol = cb * PN + 32 * wn + ucol;        // + 128 b
+                // row pointers: ONE 64-bit multiply per fragment and stream, then uniform strides (4 q rows, 128 b columns) -- the
+                // epilogue is bound by its vector-ALU instruction count, and a 64-bit row * pitch product per unit was a fifth of it
+                [[maybe_unused]] bf16* const o_bf = MODE == MODE_WIDE && EP != EP_BIAS_RESID ? p.outb + (long)mrow * p.ldob + ccol : nullptr;
+                [[maybe_unused]] bf16* const o_aux = EP == EP_BIAS_GELU_SAVE ? p.aux_out + (long)mrow * p.ld_aux + ccol : nullptr;
+                [[maybe_unused]] const bf16* const i_aux = EP == EP_DGELU ? p.aux_in + (long)mrow * p.ld_aux + ccol : nullptr;
+                [[maybe_unused]] float* const o_f32 = EP == EP_BIAS_RESID ? p.out + (long)mrow * p.ldo + ccol : nullptr;
+                [[maybe_unused]] const float* const i_res = EP == EP_BIAS_RESID ? p.resid + (long)mrow * p.ldr + ccol : nullptr;
+                const long s_ob = 4 * p.ldob, s_aux = 4 * p.ld_aux, s_of = 4 * p.ldo, s_res = 4 * p.ldr;            // (scalar registers)
                 bf16x2 ax[EP == EP_DGELU ? 12 : 1];
                 f32x2 ar[EP == EP_BIAS_RESID ? 12 : 1];
                 float rsc[EP == EP_BIAS_RESID ? 4 : 1];
@@ -402,8 +410,8 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                     for (int b = 0; b < 3; ++b)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            if constexpr (EP == EP_DGELU) ax[b * 4 + q] = *(const bf16x2*)(p.aux_in + (long)(mrow + 4 * q) * p.ld_aux + ccol + 128 * b);
-                            else ar[b * 4 + q] = *(const f32x2*)(p.resid + (long)(mrow + 4 * q) * p.ldr + ccol + 128 * b);
+                            if constexpr (EP == EP_DGELU) ax[b * 4 + q] = *(const bf16x2*)(i_aux + q * s_aux + 128 * b);
+                            else ar[b * 4 + q] = *(const f32x2*)(i_res + q * s_res + 128 * b);
                         }
                     if constexpr (EP == EP_BIAS_RESID) {
 #pragma unroll
@@ -424,8 +432,6 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                     for (int q = 0; q < 4; ++q) {
                         const f32x2 t2 = *(GV_LDS f32x2*)(wimg + (4 * q + urow) * RS + 32 * b + ucol);       // (a wave's LDS accesses execute in order)
                         float v0 = t2[0], v1 = t2[1];
-                        const long m = mrow + 4 * q;
-                        const int col = ccol + 128 * b;
 #ifdef GV_LAB_WIDE_NOSTORE      // lab: image transit + epilogue arithmetic, no global stores
                         if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v0 = gelu_f(v0); v1 = gelu_f(v1); }
                         if constexpr (EP == EP_DGELU) { v0 *= dgelu_f((float)ax[b * 4 + q][0]); v1 *= dgelu_f((float)ax[b * 4 + q][1]); }
@@ -433,17 +439,17 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                         if (true) continue;
 #endif
                         if constexpr (EP == EP_BIAS_RESID) {
-                            *(f32x2*)(p.out + m * p.ldo + col) = f32x2{fmaf(v0, rsc[q], ar[b * 4 + q][0]), fmaf(v1, rsc[q], ar[b * 4 + q][1])};
+                            *(f32x2*)(o_f32 + q * s_of + 128 * b) = f32x2{fmaf(v0, rsc[q], ar[b * 4 + q][0]), fmaf(v1, rsc[q], ar[b * 4 + q][1])};
                         } else {
                             if constexpr (EP == EP_BIAS_GELU_SAVE) {
                                 // nontemporal: the saved pre-activation is not read again before the backward pass; kept out of the
                                 // caches, more of h (the next kernel's A operand, written beside it) is still in L2 / Infinity Cache
                                 // when fc2 reads it (round 2: fc2 + LayerNorm forward 99 -> 89 us)
-                                __builtin_nontemporal_store(bf16x2{(bf16)v0, (bf16)v1}, (bf16x2*)(p.aux_out + m * p.ld_aux + col));
+                                __builtin_nontemporal_store(bf16x2{(bf16)v0, (bf16)v1}, (bf16x2*)(o_aux + q * s_aux + 128 * b));
                             }
                             if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v0 = gelu_f(v0); v1 = gelu_f(v1); }
                             if constexpr (EP == EP_DGELU) { v0 *= dgelu_f((float)ax[b * 4 + q][0]); v1 *= dgelu_f((float)ax[b * 4 + q][1]); }
-                            bf16x2* dst = (bf16x2*)(p.outb + m * p.ldob + col);
+                            bf16x2* dst = (bf16x2*)(o_bf + q * s_ob + 128 * b);
 #ifdef GV_LAB_WIDE_NT
                             __builtin_nontemporal_store(bf16x2{(bf16)v0, (bf16)v1}, dst);
 #else
