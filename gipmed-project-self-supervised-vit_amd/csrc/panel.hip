@@ -512,45 +512,60 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         const int slot = rr >> 1, h = slot / IBH, ii = slot % IBH;
         return 16 * (h * FMH + i0 + ii) + 8 * (rr & 1);
     };
-    if constexpr (MODE != MODE_WIDE) { PSTAMP(3); }
-    if constexpr (MODE != MODE_WIDE)
-#pragma unroll
-    for (int i0 = 0; i0 < (PP ? FMH : FM); i0 += (PP ? IBH : IB)) {
-        const int ni = PP ? ((FMH - i0) < IBH ? (FMH - i0) : IBH) : ((FM - i0) < IB ? (FM - i0) : IB);          // compile-time after unrolling
-        // ---- this wave's global rows of the pass (clamped at M: surplus rows load valid memory and are never stored)
-        f32x2 pre_a[MODE == MODE_WIDE && EP != EP_BIAS_RESID ? 1 : RPW][3], pre_b[MODE == MODE_BWD ? RPW : 1][3];
-        float pre_mean[MODE == MODE_BWD ? RPW : 1], pre_rstd[MODE == MODE_BWD ? RPW : 1];
-        bf16x2 pre_x[MODE == MODE_WIDE && EP == EP_DGELU ? RPW : 1][3];
+    if constexpr (MODE != MODE_WIDE) {
+    PSTAMP(3);
+    // The row phase is HBM-bound (s_memtime stamps, tools/panel_stamps.py: forward 170 MB, backward 237 MB per launch at 5.6 - 5.9
+    // TB/s, as long as the k-loop).  Lab switch GV_LAB_EPI_PIPELINE requests the rows of pass p + 1 right behind pass p's image
+    // barrier -- ahead of pass p's stores, into a second register set -- on the theory that a wave's memory operations retire in
+    // order and read bursts therefore wait for write bursts: measured on one box against this ordering (tools/panel_bench.py,
+    // round 3), forward 44.6 - 47.7 vs 45.9 - 47.7 us (K = 384), 88 - 92 vs 89 - 90 (K = 1536), backward 59 vs 54 (K = 384), 95 vs
+    // 94 - 98 (K = 1536): nothing, and the variants that start at pass 0 spill 44 - 92 B per lane and lose 10 %.  Not a burst effect.
+    constexpr int PSTEP = PP ? IBH : IB, NPASS = ((PP ? FMH : FM) + PSTEP - 1) / PSTEP;
+    // first pass that requests its successor's rows early: the largest panels have no registers for it while most accumulators
+    // are still live (forward: from pass 1 of 3; backward: from pass 2 of 6 -- earlier spills 44 - 92 B per lane)
+#ifndef GV_EPI_PIPE0_FWD
+#define GV_EPI_PIPE0_FWD 1
+#define GV_EPI_PIPE0_BWD 2
+#endif
+    constexpr int EPI_PIPE0 = FM >= 9 ? (MODE == MODE_FWD ? GV_EPI_PIPE0_FWD : GV_EPI_PIPE0_BWD) : 0;
+    f32x2 pre_a[2][RPW][3], pre_b[2][MODE == MODE_BWD ? RPW : 1][3];
+    float pre_mean[2][MODE == MODE_BWD ? RPW : 1], pre_rstd[2][MODE == MODE_BWD ? RPW : 1];
+    auto prefetch = [&](auto Pc) {
+        constexpr int ps = decltype(Pc)::value, i0 = ps * PSTEP, S = ps & 1;
+        constexpr int ni = ((PP ? FMH : FM) - i0) < PSTEP ? ((PP ? FMH : FM) - i0) : PSTEP;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             if (row_valid(i0, ni, rr)) {
                 int m = m0 + row_off(i0, rr) + wave;
-                m = m < M ? m : M - 1;
+                m = m < M ? m : M - 1;                            // clamped at M: surplus rows load valid memory and are never stored
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int col = (c * 64 + lane) * 2;
-                    if constexpr (MODE == MODE_WIDE) {
-                        if constexpr (EP == EP_BIAS_RESID) pre_a[rr][c] = *(const f32x2*)(p.resid + (long)m * p.ldr + cb * PN + col);
-#ifdef GV_NT_AUX_LD
-                        if constexpr (EP == EP_DGELU) pre_x[rr][c] = __builtin_nontemporal_load((const bf16x2*)(p.aux_in + (long)m * p.ld_aux + cb * PN + col));
-#else
-                        if constexpr (EP == EP_DGELU) pre_x[rr][c] = *(const bf16x2*)(p.aux_in + (long)m * p.ld_aux + cb * PN + col);
-#endif
-                    } else if constexpr (MODE == MODE_FWD) {
-                        pre_a[rr][c] = p.resid ? *(const f32x2*)(p.resid + (long)m * p.ldr + col) : f32x2{0.f, 0.f};
+                    if constexpr (MODE == MODE_FWD) {
+                        pre_a[S][rr][c] = p.resid ? *(const f32x2*)(p.resid + (long)m * p.ldr + col) : f32x2{0.f, 0.f};
                     } else {
 #ifdef GV_NT_X          // lab: the LayerNorm input row is read here for the last time in the step
-                        pre_a[rr][c] = __builtin_nontemporal_load((const f32x2*)(p.x + (long)m * p.ldx + col));
+                        pre_a[S][rr][c] = __builtin_nontemporal_load((const f32x2*)(p.x + (long)m * p.ldx + col));
 #else
-                        pre_a[rr][c] = *(const f32x2*)(p.x + (long)m * p.ldx + col);
+                        pre_a[S][rr][c] = *(const f32x2*)(p.x + (long)m * p.ldx + col);
 #endif
-                        pre_b[rr][c] = p.g_init ? f32x2{0.f, 0.f} : *(const f32x2*)(p.g + (long)m * p.ldg + col);
+                        pre_b[S][rr][c] = p.g_init ? f32x2{0.f, 0.f} : *(const f32x2*)(p.g + (long)m * p.ldg + col);
                     }
                 }
-                if constexpr (MODE == MODE_BWD) { pre_mean[rr] = p.mean[m]; pre_rstd[rr] = p.rstd[m]; }
+                if constexpr (MODE == MODE_BWD) { pre_mean[S][rr] = p.mean[m]; pre_rstd[S][rr] = p.rstd[m]; }
             }
         }
-        if (i0 == 0) __syncthreads();                             // every wave is past the ring: it is image space now
+    };
+    prefetch(std::integral_constant<int, 0>{});
+    static_for<0, NPASS>([&](auto Pc) {
+        constexpr int ps = decltype(Pc)::value, i0 = ps * PSTEP, S = ps & 1;
+        constexpr int ni = ((PP ? FMH : FM) - i0) < PSTEP ? ((PP ? FMH : FM) - i0) : PSTEP;
+#ifdef GV_LAB_EPI_PIPELINE
+        if constexpr (ps >= 1 && ps - 1 < EPI_PIPE0) prefetch(Pc);       // not requested early (see below)
+#else
+        if constexpr (ps >= 1) prefetch(Pc);
+#endif
+        if constexpr (i0 == 0) __syncthreads();                   // every wave is past the ring: it is image space now
         // ---- accumulators -> LDS image [rows of this pass][384 columns] f32
         if constexpr (PP) {
 #pragma unroll
@@ -568,18 +583,26 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
             }
         } else {
 #pragma unroll
-        for (int ii = 0; ii < IB; ++ii) {
-            if (ii < ni) {
+            for (int ii = 0; ii < IB; ++ii) {
+                if (ii < ni) {
 #pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    f32x4 v = acc[i0 + ii][j];
-                    if constexpr (HAS_BIAS) v += bias4[j];
-                    *(GV_LDS f32x4*)(img + (ii * 16 + li16) * IMG_STRIDE + 16 * (NW * j + wave) + gq * 4) = v;
+                    for (int j = 0; j < NF; ++j) {
+                        f32x4 v = acc[i0 + ii][j];
+                        if constexpr (HAS_BIAS) v += bias4[j];
+                        *(GV_LDS f32x4*)(img + (ii * 16 + li16) * IMG_STRIDE + 16 * (NW * j + wave) + gq * 4) = v;
+                    }
                 }
             }
         }
-        }
         __syncthreads();
+        // (pass 0 still holds most of the accumulators: its successor's rows are requested at the top of pass 1, as before --
+        //  requesting them here overflows the register file by ~20 registers at FM = 11 / 12)
+#ifdef GV_LAB_EPI_PIPELINE
+        if constexpr (ps + 1 < NPASS && ps >= EPI_PIPE0) prefetch(std::integral_constant<int, ps + 1>{});     // ahead of this pass's stores
+#else
+        if constexpr (false) {}
+#endif
+
         // ---- one wave per row
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
@@ -593,38 +616,12 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                         const f32x2 t2 = *(GV_LDS f32x2*)(img + r * IMG_STRIDE + (c * 64 + lane) * 2);
                         v[c][0] = t2[0]; v[c][1] = t2[1];
                     }
-                    if constexpr (MODE == MODE_WIDE && EP == EP_BIAS_RESID) {
-                        float* orow = p.out + (long)m * p.ldo + cb * PN;
-                        const float rs = p.row_scale ? p.row_scale[m] : 1.0f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            *(f32x2*)(orow + (c * 64 + lane) * 2) = f32x2{fmaf(v[c][0], rs, pre_a[rr][c][0]), fmaf(v[c][1], rs, pre_a[rr][c][1])};
-                    } else if constexpr (MODE == MODE_WIDE) {
-                        bf16* orow = p.outb + (long)m * p.ldob + cb * PN;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const int col = (c * 64 + lane) * 2;
-                            if constexpr (EP == EP_BIAS_GELU_SAVE) {
-                                // nontemporal: the saved pre-activation is not read again before the backward pass; kept out of the
-                                // caches, more of h (the next kernel's A operand, written beside it) is still in L2 / Infinity Cache
-                                // when fc2 reads it: fc2 + LayerNorm forward 99 -> 89 us, step -1.5 % (tools/nt_aux_lab.sh)
-                                __builtin_nontemporal_store(bf16x2{(bf16)v[c][0], (bf16)v[c][1]}, (bf16x2*)(p.aux_out + (long)m * p.ld_aux + cb * PN + col));
-                            }
-                            if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v[c][0] = gelu_f(v[c][0]); v[c][1] = gelu_f(v[c][1]); }
-                            if constexpr (EP == EP_DGELU) { v[c][0] *= dgelu_f((float)pre_x[rr][c][0]); v[c][1] *= dgelu_f((float)pre_x[rr][c][1]); }
-                            // The output streams through the 4-MB L2 of the XCD and evicts what the workgroups re-read: their A
-                            // panels (32 per XCD x 16 FM rows x 768 B, fetched once per column block).  Up to FM = 8 the panels
-                            // fit L2 beside the weights -- if the output is stored nontemporally (the teacher's fc1 / qkv, FM = 7:
-                            // 63 -> 54 us, 46 -> 39 us); at FM = 11 they do not fit anyway and the hint costs 1 - 2 us.
-                            if constexpr (FM <= 8) __builtin_nontemporal_store(bf16x2{(bf16)v[c][0], (bf16)v[c][1]}, (bf16x2*)(orow + col));
-                            else *(bf16x2*)(orow + col) = bf16x2{(bf16)v[c][0], (bf16)v[c][1]};
-                        }
-                    } else if constexpr (MODE == MODE_FWD) {
+                    if constexpr (MODE == MODE_FWD) {
                         float* orow = p.out + (long)m * p.ldo;
                         const float rs = p.row_scale ? p.row_scale[m] : 1.0f;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            v[c][0] = fmaf(v[c][0], rs, pre_a[rr][c][0]); v[c][1] = fmaf(v[c][1], rs, pre_a[rr][c][1]);
+                            v[c][0] = fmaf(v[c][0], rs, pre_a[S][rr][c][0]); v[c][1] = fmaf(v[c][1], rs, pre_a[S][rr][c][1]);
 #ifdef GV_NT_XOUT     // lab: the f32 residual row is read again two kernels later (epilogue, prefetched) -- leave the cache to h / qkv
                             __builtin_nontemporal_store(f32x2{v[c][0], v[c][1]}, (f32x2*)(orow + (c * 64 + lane) * 2));
 #else
@@ -655,15 +652,15 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                     } else {
                         // LayerNorm backward of this row: v = dy (the dX product, still f32)
                         float* grow = p.g + (long)m * p.ldg;
-                        const float mean = pre_mean[rr], rstd = pre_rstd[rr];
+                        const float mean = pre_mean[S][rr], rstd = pre_rstd[S][rr];
                         float xh[3][2], wdy[3][2], gv[3][2];
                         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
 #pragma unroll
                             for (int e = 0; e < 2; ++e) {
-                                gv[c][e] = pre_b[rr][c][e];
-                                xh[c][e] = (pre_a[rr][c][e] - mean) * rstd;
+                                gv[c][e] = pre_b[S][rr][c][e];
+                                xh[c][e] = (pre_a[S][rr][c][e] - mean) * rstd;
                                 wdy[c][e] = v[c][e] * gm[c][e];
                                 c1 += wdy[c][e];
                                 c2 += wdy[c][e] * xh[c][e];
@@ -693,6 +690,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
             }
         }
         __syncthreads();                                          // image free for the next pass / the reduction below
+    });
     }
     if constexpr (MODE != MODE_WIDE) { PSTAMP(6); }
     if constexpr (MODE == MODE_WIDE) {                            // next row panel (its tile 0 went out as tile nt of this panel's stream)
