@@ -118,7 +118,7 @@ ENTRY_POINTS = {
     "gv_tokens_bwd_f32": gv_tokens_bwd_args, "gv_l2norm_fwd_f32": gv_l2norm_fwd_args, "gv_l2norm_bwd_f32": gv_l2norm_bwd_args,
     "gv_weightnorm_fwd_f32": gv_weightnorm_fwd_args, "gv_dino_loss_f32": gv_dino_loss_args,
 }
-PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read",
+PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes", "gv_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read",
                  "gv_linear_ln_blocks")
 
 
@@ -127,6 +127,7 @@ class gv_linear_timing_row(C.Structure):
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_POS, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 LN_PARTIAL_BLOCKS = 1024
+OP_LINEAR, OP_LINEAR_DW_GROUP = 0, 1
 HYP_LR, HYP_WD, HYP_BC1, HYP_BC2, HYP_TEACHER_MOM, HYP_GRAD_SCALE, HYP_TEACHER_TEMP, HYP_STUDENT_TEMP, HYP_COUNT = range(9)
 
 
@@ -148,6 +149,8 @@ def _load():
     lib.gv_last_error.restype = C.c_char_p
     lib.gv_target.restype = C.c_char_p
     lib.gv_linear_workspace_bytes.restype = C.c_int64
+    lib.gv_workspace_bytes.argtypes = [C.c_int32, vp]
+    lib.gv_workspace_bytes.restype = C.c_int64
     lib.gv_linear_timing.argtypes = [C.c_int]
     lib.gv_linear_timing.restype = C.c_int
     lib.gv_linear_timing_read.argtypes = [C.POINTER(gv_linear_timing_row), C.c_int]

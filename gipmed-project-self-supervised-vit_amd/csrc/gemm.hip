@@ -158,6 +158,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const ReduceGr
 }
 
 constexpr long WORKSPACE_BYTES = 128L << 20;
+// gv_workspace_bytes: the entry points run their own kernel selection and k-slice sizing in PLAN mode -- nothing is launched, the
+// scratch the call would use is recorded instead (so the answer cannot drift from what a launch does)
+thread_local bool g_plan = false;
+thread_local long g_plan_bytes = 0;
 
 // k-slices for `tiles` one-per-CU workgroups over `ktiles` 64-deep K-tiles: the S that minimises  rounds of 256 workgroups x
 // K-tiles per slice  (ViT-S block: 36 tiles -> S = 7, one round; ViT-B block: 144 tiles -> S = 3, two rounds of 2/3 the
@@ -228,6 +232,7 @@ int try_dw8(const gv_linear_args* a, hipStream_t s) {
     const int per = (ktiles + S - 1) / S;
     S = (ktiles + per - 1) / per;
     if ((long)S * a->M * a->N * 4 > a->workspace_bytes) return -1;
+    if (g_plan) { g_plan_bytes = (long)S * a->M * a->N * 4; return GV_OK; }
     q.ksplit = S; q.k_per_split = per * 64;
     return normal ? launch_dw8<false>(q, (float*)a->C, a->ldc, a->M, a->N, s) : launch_dw8<true>(q, (float*)a->C, a->ldc, a->M, a->N, s);
 }
@@ -235,6 +240,27 @@ int try_dw8(const gv_linear_args* a, hipStream_t s) {
 }  // namespace
 
 extern "C" int64_t gv_linear_workspace_bytes(void) { return WORKSPACE_BYTES; }
+
+extern "C" int64_t gv_workspace_bytes(int32_t op, const void* args) {
+    if (!args) { gv_set_error("gv_workspace_bytes: null args"); return -1; }
+    g_plan = true; g_plan_bytes = 0;
+    int rc;
+    if (op == GV_OP_LINEAR) {
+        gv_linear_args a = *(const gv_linear_args*)args;
+        a.workspace = (float*)(uintptr_t)256; a.workspace_bytes = WORKSPACE_BYTES;      // "as if the full scratch were offered" (never dereferenced)
+        rc = gv_linear(&a, nullptr);
+    } else if (op == GV_OP_LINEAR_DW_GROUP) {
+        gv_linear_dw_group_args a = *(const gv_linear_dw_group_args*)args;
+        a.workspace = (float*)(uintptr_t)256; a.workspace_bytes = WORKSPACE_BYTES;
+        rc = gv_linear_dw_group(&a, nullptr);
+    } else {
+        g_plan = false;
+        gv_set_error("gv_workspace_bytes: op %d takes no scratch query (GV_OP_LINEAR, GV_OP_LINEAR_DW_GROUP)", op);
+        return -1;
+    }
+    g_plan = false;
+    return rc == GV_OK ? (int64_t)g_plan_bytes : -1;
+}
 #ifdef GV_DW8_STAMPS   // tuning-lab build only (tools/dw_bench.py)
 extern "C" int gv_dw8_dbg_read(unsigned long long* host) { if (!g_dw8_dbg) return -1; return (int)hipMemcpy(host, g_dw8_dbg, 256 * 8 * 8 * 8, hipMemcpyDeviceToHost); }
 #endif
@@ -333,7 +359,7 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     {
         int rc = try_dw8(a, (hipStream_t)stream);
         if (rc != -1) return rc;
-        rc = gv_panel_wide(a, (hipStream_t)stream);
+        rc = gv_panel_wide(a, g_plan ? (hipStream_t)(intptr_t)-1 : (hipStream_t)stream);      // ((hipStream_t)-1: "would this call run there?")
         if (rc != -1) return rc;
     }
     GemmP p;
@@ -372,6 +398,7 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
             }
         }
     }
+    if (g_plan) { g_plan_bytes = p.ksplit > 1 ? (long)p.ksplit * a->M * a->N * 4 : 0; return GV_OK; }
     bool slab = false;
     if (p.ksplit > 1 && a->workspace && (long)p.ksplit * a->M * a->N * 4 <= a->workspace_bytes && gv_aligned(a->workspace, 16)) {
         p.slab = a->workspace;
@@ -462,6 +489,7 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
             for (int q = a->n; q <= GV_DW_GROUP_MAX; ++q) G8.tile_base[q] = tb;
             G8.total_tiles = tb;
             if (slab_floats * 4 <= a->workspace_bytes) {
+                if (g_plan) { g_plan_bytes = slab_floats * 4; return GV_OK; }
                 static GvLdsOptIn opt_in8;
                 if (int rc = gv_lds_opt_in(opt_in8, (const void*)dw8_group_kernel, DW8_LDS, "gv_linear_dw_group")) return rc;
                 const int th = gvtime::enabled() ? gvtime::begin("dw8_group_kernel", flops, bytes, s) : -1;
@@ -519,6 +547,7 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
         p.slab = a->workspace + slab_floats;
         slab_floats += (long)ksplit * p.M * p.N;
     }
+    if (g_plan) { g_plan_bytes = slab_floats * 4; return GV_OK; }
     GV_REQUIRE(slab_floats * 4 <= a->workspace_bytes, GV_E_SHAPE, "gv_linear_dw_group: workspace too small (%ld bytes needed)", slab_floats * 4);
     static GvLdsOptIn opt_in;
     if (int rc = gv_lds_opt_in(opt_in, (const void*)gemm_dw_group_kernel, PCfg::LDS, "gv_linear_dw_group")) return rc;

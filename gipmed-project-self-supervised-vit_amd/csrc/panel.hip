@@ -806,9 +806,11 @@ int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
 int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
     if (a->trans_a || a->N % PN != 0 || a->K % 128 != 0 || a->M < 2048 || a->ldc % 2 != 0) return -1;
     if (a->alpha != 0.f && a->alpha != 1.f) return -1;
+    const bool plan = s == (hipStream_t)(intptr_t)-1;       // gv_workspace_bytes: "would this call run here?" (these kernels take no scratch)
     if (a->c_is_f32) {      // x + Linear(a) with an f32 residual stream, where no fused LayerNorm kernel exists for the width
         if (a->trans_b || a->epilogue != (GV_EPI_BIAS | GV_EPI_RESID) || a->ldr % 2 != 0) return -1;
         if ((const void*)a->resid == (const void*)a->C) return -1;      // in place: the rows the last two panels share would be updated twice
+        if (plan) return GV_OK;
         PanelP q{};
         q.A = (const bf16*)a->A; q.W = (const bf16*)a->B; q.M = a->M; q.K = a->K; q.lda = a->lda; q.ldw = a->ldb;
         q.bias = a->bias; q.out = (float*)a->C; q.ldo = a->ldc; q.resid = a->resid; q.ldr = a->ldr; q.row_scale = a->row_scale;
@@ -821,6 +823,10 @@ int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
     p.ncb = a->N / PN; p.n_total = a->N;
     if (a->ld_aux % 2 != 0) return -1;
     const int e = a->epilogue;
+    if (plan) {
+        const bool fwd = !a->trans_b && (e == GV_EPI_BIAS || e == (GV_EPI_BIAS | GV_EPI_GELU) || e == (GV_EPI_BIAS | GV_EPI_GELU | GV_EPI_SAVE_PRE));
+        return (fwd || (a->trans_b && (e == 0 || e == GV_EPI_DGELU))) ? GV_OK : -1;
+    }
     if (!a->trans_b) {
         if (e == GV_EPI_BIAS) return dispatch_fm<false, MODE_WIDE, EP_BIAS>(p, s, "gv_linear(wide)");
         if (e == (GV_EPI_BIAS | GV_EPI_GELU)) return dispatch_fm<false, MODE_WIDE, EP_BIAS_GELU>(p, s, "gv_linear(wide)");

@@ -236,8 +236,17 @@ typedef struct {
      * --drop-path: keep / (1 - p) of the token's image, see gv_expand_rows); NULL = 1                                  */
     const float* row_scale;
 } gv_linear_args;
-/* upper bound of the split-K scratch gv_linear can use for any shape: 64 MiB */
+/* upper bound of the split-K scratch gv_linear can use for any shape */
 int64_t gv_linear_workspace_bytes(void);
+/* Scratch ONE call would use if the full gv_linear_workspace_bytes() were offered (`gv_workspace_bytes(op, shape)`):
+ * op = GV_OP_LINEAR with a gv_linear_args, GV_OP_LINEAR_DW_GROUP with a gv_linear_dw_group_args -- shapes, flags, leading
+ * dimensions and operand ALIGNMENT as in the real call (pointers are checked for alignment, never dereferenced; the
+ * workspace fields are ignored).  The entry point's own kernel selection runs in a plan mode, nothing is launched: 0 = the call
+ * takes no scratch (e.g. the full-row kernels), -1 = the arguments would be rejected (gv_last_error()).  Every other entry
+ * point takes caller-sized buffers named in its struct and needs no query.                                                  */
+#define GV_OP_LINEAR 0
+#define GV_OP_LINEAR_DW_GROUP 1
+int64_t gv_workspace_bytes(int32_t op, const void* args);
 int gv_linear(const gv_linear_args* a, void* stream);
 
 /* Weight gradients of several Linears that reduce over the SAME token rows (one transformer block: attn.qkv, attn.proj,

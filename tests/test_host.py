@@ -74,6 +74,33 @@ def test_bad_arguments_fail_loudly_without_gpu():
             cls(precision="fp16", device="cpu")
 
 
+def test_workspace_query_runs_the_entry_points_in_plan_mode():
+    """gv_workspace_bytes(op, args): the scratch one call would use, answered by the entry point's own kernel selection
+    and k-slice sizing in a plan mode -- nothing is launched, no GPU is touched."""
+    from gipvit import _lib
+    q = lambda op, a: _lib.lib.gv_workspace_bytes(op, ctypes.byref(a))
+    P = 1 << 20                                                        # any 16-byte aligned non-null value: never dereferenced
+    T, D = 44160, 384
+    dw = _lib.gv_linear_args(); dw.A = dw.B = dw.C = P
+    dw.M, dw.N, dw.K, dw.lda, dw.ldb, dw.ldc = 4 * D, D, T, 4 * D, D, D
+    dw.trans_a = dw.trans_b = dw.c_is_f32 = 1; dw.epilogue = _lib.EPI_ACCUM
+    b = q(_lib.OP_LINEAR, dw)
+    assert 0 < b <= _lib.lib.gv_linear_workspace_bytes() and b % (4 * D * D * 4) == 0, b      # S slabs of M x N f32
+    wide = _lib.gv_linear_args(); wide.A = wide.B = wide.C = wide.bias = P
+    wide.M, wide.N, wide.K, wide.lda, wide.ldb, wide.ldc = T, 4 * D, D, D, D, 4 * D
+    wide.epilogue = _lib.EPI_BIAS
+    assert q(_lib.OP_LINEAR, wide) == 0                                # the full-row kernel takes no scratch
+    grp = _lib.gv_linear_dw_group_args(); grp.n, grp.K = 4, T
+    for pr, (m, n) in zip(grp.prob, ((D, 4 * D), (4 * D, D), (D, D), (3 * D, D))):
+        pr.dY = pr.X = pr.dW = P; pr.M, pr.N, pr.ldy, pr.ldx, pr.ldw = m, n, m, n, n
+    g = q(_lib.OP_LINEAR_DW_GROUP, grp)
+    mn = 4 * (D * 4 * D + 4 * D * D + D * D + 3 * D * D)
+    assert g == 7 * mn, (g, mn)                                        # 36 tiles x 7 k-slices = 252 workgroups: DESIGN section 4's 50-MB slab
+    assert q(7, wide) == -1 and b"GV_OP_LINEAR" in _lib.lib.gv_last_error()
+    bad = _lib.gv_linear_args()                                        # null operands: the call itself would be rejected
+    assert q(_lib.OP_LINEAR, bad) == -1
+
+
 def test_arena_layout_and_decay_split():
     from collections import OrderedDict
     from gipvit import engine as E
