@@ -95,7 +95,7 @@ gv_sumsq_args = _struct("gv_sumsq_args", [("x", vp), ("n", i64), ("workspace", v
 gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
     ("p", vp), ("grad", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("teacher", vp), ("teacher_bf16", vp), ("n", i64),
     ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bias_corr1", f32), ("bias_corr2", f32),
-    ("grad_scale", f32), ("clip_norm", f32), ("gnorm_sq", vp), ("teacher_momentum", f32), ("hyper", vp), ("mode", i32)])
+    ("grad_scale", f32), ("clip_norm", f32), ("gnorm_sq", vp), ("teacher_momentum", f32), ("hyper", vp), ("mode", i32), ("clip_value", f32)])
 gv_lamb_args = _struct("gv_lamb_args", [
     ("p", vp), ("grad", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("teacher", vp), ("teacher_bf16", vp), ("blocks", vp), ("n_blocks", i32),
     ("stats", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bias_corr1", f32), ("bias_corr2", f32),

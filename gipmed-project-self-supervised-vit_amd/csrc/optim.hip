@@ -26,6 +26,10 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
     const long n4 = a.n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 g = ((const f32x4*)a.grad)[i] * gscale;
+        if (a.clip_value > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = fminf(fmaxf(g[j], -a.clip_value), a.clip_value);
+        }
         f32x4 p = ((f32x4*)a.p)[i], m = ((f32x4*)a.m)[i], v = ((f32x4*)a.v)[i];
         if (a.mode == 3) {
             // frozen range (no gradient: the optimizer skips the parameter); only the EMA below runs
@@ -129,6 +133,7 @@ extern "C" int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream) {
     GV_REQUIRE(gv_aligned(a->p, 16) && gv_aligned(a->grad, 16) && gv_aligned(a->m, 16) && gv_aligned(a->v, 16), GV_E_ALIGN,
                "gv_adamw_ema: buffers must be 16-byte aligned");
     if (a->clip_norm > 0.f) GV_REQUIRE(a->gnorm_sq, GV_E_NULL, "gv_adamw_ema: clip_norm needs gnorm_sq");
+    GV_REQUIRE(!(a->clip_norm > 0.f && a->clip_value > 0.f), GV_E_UNSUPPORTED, "gv_adamw_ema: clip_norm and clip_value exclude each other (--clip-mode norm | value)");
     if (!a->hyper) GV_REQUIRE(a->bias_corr1 > 0.f && a->bias_corr2 > 0.f, GV_E_SHAPE, "gv_adamw_ema: bias corrections must be > 0");
     long blocks = (a->n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);

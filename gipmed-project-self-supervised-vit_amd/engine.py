@@ -625,9 +625,13 @@ class DinoEngine:
     def __init__(self, arch="vit_small", img_size=224, out_dim=65536, batch=64, tile=256, n_global=2, n_local=8,
                  gsize=224, lsize=96, hidden=2048, bottleneck=256, lr=5e-4, weight_decay=0.04, betas=(0.9, 0.999), eps=1e-8,
                  momentum_teacher=0.996, student_temp=0.1, teacher_temp=0.04, center_momentum=0.9, clip_grad: float = 0.0,
-                 mean=MEAN_RON, std=STD_RON, windows=None, device="cuda:0", reducer=None, precision: str = "bf16"):
+                 mean=MEAN_RON, std=STD_RON, windows=None, device="cuda:0", reducer=None, precision: str = "bf16", clip_mode: str = "norm"):
         """``precision``: "bf16" (the training path) or "fp32" (every GEMM / attention operand, the head activations, the
-        weight-normalised prototype matrix and the logit gradient in f32 -- the verification mode of SURVEY 8d's fp32 column)."""
+        weight-normalised prototype matrix and the logit gradient in f32 -- the verification mode of SURVEY 8d's fp32 column).
+        ``clip_mode``: "norm" (global norm, the reference default) or "value" (element-wise clamp), train.py:1072-1077."""
+        if clip_mode not in ("norm", "value"):
+            raise ValueError(f"clip_mode {clip_mode!r}: 'norm' or 'value'")
+        self.clip_mode = clip_mode
         if precision not in ("bf16", "fp32"):
             raise ValueError(f"precision {precision!r}: 'bf16' or 'fp32'")
         fp32 = precision == "fp32"
@@ -844,10 +848,12 @@ class DinoEngine:
 
     def optimizer_step(self):
         a = self.arena
-        if self.clip > 0:
+        by_norm = self.clip > 0 and self.clip_mode == "norm"
+        if by_norm:
             ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
         kw = dict(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=max(self.t, 1),
-                  clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None, hyper=self.hyper)
+                  clip_norm=self.clip if by_norm else 0.0, gnorm_sq=self.gnorm_sq if by_norm else None, hyper=self.hyper,
+                  clip_value=self.clip if (self.clip > 0 and self.clip_mode == "value") else 0.0)
         lo = 0
         if not self.train_last_layer:
             # the head's last layer is frozen for the first epochs (DINO cancel_gradients_last_layer sets its grad to
@@ -902,12 +908,17 @@ class SupervisedEngine:
     def __init__(self, arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999),
                  eps=1e-8, smoothing=0.1, clip_grad: float = 0.0, mean=MEAN_RON, std=STD_RON, device="cuda:0", reducer=None,
                  opt: str = "adamw", momentum: float = 0.9, train_backbone: bool = True, model_ema_decay: Optional[float] = None,
-                 precision: str = "bf16"):
+                 precision: str = "bf16", clip_mode: str = "norm"):
         """``precision``: "bf16" (the training path: bf16 GEMM / attention operands, f32 accumulation and residual stream) or
         "fp32" (the reference's default arithmetic: every operand f32, csrc/f32path.hip -- the mode the 1e-4 parity gates
         of SURVEY 8d are stated for; an order of magnitude slower, kept for verification)."""
         if precision not in ("bf16", "fp32"):
             raise ValueError(f"precision {precision!r}: 'bf16' or 'fp32'")
+        if clip_mode not in ("norm", "value"):
+            raise ValueError(f"clip_mode {clip_mode!r}: 'norm' or 'value' (train.py:1072-1077; 'agc' is not built)")
+        if clip_mode == "value" and opt == "lamb":
+            raise ValueError("--clip-mode value with --opt lamb is not built (Lamb's own global-norm clip needs the norm of the clamped gradient)")
+        self.clip_mode = clip_mode
         fp32 = precision == "fp32"
         act = f32 if fp32 else bf16
         self.precision = precision
@@ -1001,11 +1012,13 @@ class SupervisedEngine:
     def optimizer_step(self, lr=None):
         a = self.arena
         self.t += 1
-        if self.clip > 0:
+        by_norm = self.clip > 0 and self.clip_mode == "norm"
+        if by_norm:
             ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
         kw = dict(lr=self.lr if lr is None else lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=self.t,
-                  grad_scale=1.0 / self.reducer.world, clip_norm=self.clip, gnorm_sq=self.gnorm_sq if self.clip > 0 else None,
-                  mode=self.opt_mode, teacher_momentum=self.ema_decay or 0.0)
+                  grad_scale=1.0 / self.reducer.world, clip_norm=self.clip if by_norm else 0.0, gnorm_sq=self.gnorm_sq if by_norm else None,
+                  mode=self.opt_mode, teacher_momentum=self.ema_decay or 0.0,
+                  clip_value=self.clip if (self.clip > 0 and self.clip_mode == "value") else 0.0)
         tt = (lambda sl: (a.t[sl], a.tb[sl])) if a.t is not None else (lambda sl: (None, None))
         if self.opt_mode < 0:
             if not self.train_backbone:
@@ -1013,7 +1026,7 @@ class SupervisedEngine:
             ops.sumsq(a.g, self.red_ws, self.gnorm_sq)              # Lamb clips by the global norm itself (max_grad_norm = 1)
             self._lamb_stats.zero_()
             kl = dict(lr=kw["lr"], beta1=kw["beta1"], beta2=kw["beta2"], eps=self.eps, step=self.t, grad_scale=kw["grad_scale"],
-                      clip_norm=self.clip, max_grad_norm=self.lamb_max_grad_norm, teacher_momentum=self.ema_decay or 0.0)
+                      clip_norm=self.clip if by_norm else 0.0, max_grad_norm=self.lamb_max_grad_norm, teacher_momentum=self.ema_decay or 0.0)
             for phase in (0, 1):
                 for tab, wd in zip(self._lamb_tabs, (self.wd, 0.0)):
                     if tab.shape[0]:

@@ -328,10 +328,10 @@ def sumsq(x, workspace, out, accumulate: bool = False, n: Optional[int] = None):
 
 
 def adamw_ema(p, grad, m, v, p_bf16, teacher, teacher_bf16, n: int, *, lr, beta1, beta2, eps, weight_decay, step: int,
-              grad_scale=1.0, clip_norm=0.0, gnorm_sq=None, teacher_momentum=0.0, hyper=None, mode=0):
+              grad_scale=1.0, clip_norm=0.0, gnorm_sq=None, teacher_momentum=0.0, hyper=None, mode=0, clip_value=0.0):
     a = L.gv_adamw_ema_args(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), _p(teacher), _p(teacher_bf16), n,
                             lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
-                            grad_scale, clip_norm, _p(gnorm_sq), teacher_momentum, _p(hyper), mode)
+                            grad_scale, clip_norm, _p(gnorm_sq), teacher_momentum, _p(hyper), mode, clip_value)
     L.call("gv_adamw_ema", a, _stream())
 
 

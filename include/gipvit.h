@@ -468,6 +468,9 @@ typedef struct {
      * train.py:497-503 --no-grad, DINO's frozen last layer) and only the teacher EMA / bf16
      * refresh run.                                                                           */
     int32_t mode;
+    /* > 0: every gradient element (after grad_scale) is clamped to [-clip_value, clip_value] -- `--clip-mode value`,
+     * torch.nn.utils.clip_grad_value_ (reference train.py:1072-1077 dispatch_clip_grad); use instead of clip_norm */
+    float clip_value;
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
 

@@ -305,10 +305,10 @@ def test_every_used_flag_is_read_by_the_driver():
         elif e["flags"][0] != "data":
             assert reads == 0, f"{e['flags']} is read by train.py but marked used=False"
     # values the build cannot honour are refused before any GPU work
-    for bad in (["--drop", "0.1"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "agc"], ["--in-chans", "1"],
+    for bad in (["--drop", "0.1"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "agc"], ["--clip-mode", "value", "--opt", "lamb"], ["--in-chans", "1"],
                 ["--input-size", "3", "224", "200"], ["--dino", "--supervised"], ["--amp", "--amp-dtype", "bfloat16", "--precision", "fp32"],
                 ["--opt", "lars"], ["--opt", "rmsprop"], ["--opt", "nadam"], ["--opt", "momentum"], ["--sched", "tanh"], ["--sched", "plateau"],
-                ["--sched", "multistep"], ["--sched", "poly"], ["--dino", "--opt", "sgd"], ["--dino", "--opt", "adam"], ["--dino", "--opt", "lamb"], ["--clip-mode", "value"]):
+                ["--sched", "multistep"], ["--sched", "poly"], ["--dino", "--opt", "sgd"], ["--dino", "--opt", "adam"], ["--dino", "--opt", "lamb"]):
         args, _ = train.parse_args(["--model", "vit_tiny"] + bad)
         with pytest.raises(SystemExit):
             train.check_supported(args, lambda m: None)

@@ -553,6 +553,13 @@ def test_adamw_ema(dev):
                 clip_norm=3.0, gnorm_sq=gn)
     c = 3.0 / (math.sqrt(float(gn)) + 1e-6)
     close(m, 0.1 * grad * c, 1e-4, 1e-7, "clipped m")
+    # --clip-mode value (torch.nn.utils.clip_grad_value_): element-wise clamp of the scaled gradient
+    m.zero_(); v.zero_(); p2 = p0.clone()
+    cv = float(grad.abs().median())
+    o.adamw_ema(p2, grad, m, v, None, None, None, n, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step=1, grad_scale=0.5, clip_value=cv)
+    close(m, 0.1 * (0.5 * grad).clamp(-cv, cv), 1e-5, 1e-8, "value-clipped m")
+    with pytest.raises(L().GipvitError, match="exclude"):
+        o.adamw_ema(p2, grad, m, v, None, None, None, n, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step=1, clip_norm=1.0, gnorm_sq=gn, clip_value=1.0)
     # mode 1: Adam with L2 decay (timm --opt adam); mode 2: SGD Nesterov (timm --opt sgd)
     for mode, mk in ((1, lambda q: torch.optim.Adam([q], lr=1e-3, weight_decay=0.01)),
                      (2, lambda q: torch.optim.SGD([q], lr=1e-2, momentum=0.9, nesterov=True, weight_decay=0.01))):

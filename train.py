@@ -138,9 +138,11 @@ def check_supported(args, log=_logger.warning):
     if args.pretrained and not args.initial_checkpoint:
         raise SystemExit("--pretrained downloads weights by URL (reference train.py:482-485): there is no network here -- "
                          "pass the file with --initial-checkpoint instead")
-    if args.clip_mode != "norm":
-        raise SystemExit(f"--clip-mode {args.clip_mode}: only global-norm clipping ('norm', the reference default, train.py:1072-1077) is fused "
-                         "into the optimizer kernel")
+    if args.clip_mode not in ("norm", "value"):
+        raise SystemExit(f"--clip-mode {args.clip_mode}: 'norm' (global norm, the reference default) and 'value' (element-wise clamp) are fused into the "
+                         "optimizer kernel (train.py:1072-1077); 'agc' is not built")
+    if args.clip_mode == "value" and args.opt.lower() == "lamb":
+        raise SystemExit("--clip-mode value with --opt lamb is not built (Lamb's own global-norm clip needs the norm of the clamped gradient)")
     if args.opt.lower() not in SUPPORTED_OPTS:
         raise SystemExit(f"--opt {args.opt}: the fused optimizer kernel (csrc/optim.hip) implements {' / '.join(SUPPORTED_OPTS)}; timm's other "
                          "create_optimizer_v2 choices (reference train.py:161, 583) are not built and nothing is substituted for them")
@@ -288,7 +290,7 @@ def main(argv=None):
         eng = DinoEngine(arch=arch, img_size=img, out_dim=args.out_dim, batch=B, tile=tile, n_local=args.local_crops_number,
                          gsize=args.global_crop_size, lsize=args.local_crop_size, lr=lr, weight_decay=args.weight_decay, betas=betas, eps=eps,
                          momentum_teacher=args.momentum_teacher, teacher_temp=args.teacher_temp, clip_grad=args.clip_grad or 0.0,
-                         mean=mean, std=std, device=dev, reducer=reducer, precision=args.precision)
+                         mean=mean, std=std, device=dev, reducer=reducer, precision=args.precision, clip_mode=args.clip_mode)
         bb = (M.load_encoder_checkpoint(args.initial_checkpoint, arch, img) if args.initial_checkpoint
               else M.init_vit_state(arch, img, 0, seed=args.seed))
         eng.load_state(bb, M.init_dino_head_state(eng.D, args.out_dim, seed=args.seed + 1))
@@ -299,7 +301,7 @@ def main(argv=None):
         eng = SupervisedEngine(arch=arch, img_size=img, num_classes=nc, batch=B, lr=lr, weight_decay=args.weight_decay, betas=betas, eps=eps,
                                smoothing=args.smoothing, clip_grad=args.clip_grad or 0.0, mean=mean, std=std, device=dev, reducer=reducer,
                                opt=opt, momentum=args.momentum,
-                               train_backbone=not args.no_grad, model_ema_decay=ema_decay, precision=args.precision)
+                               train_backbone=not args.no_grad, model_ema_decay=ema_decay, precision=args.precision, clip_mode=args.clip_mode)
         st = (M.load_encoder_checkpoint(args.initial_checkpoint, arch, img, nc) if args.initial_checkpoint
               else M.init_vit_state(arch, img, nc, seed=args.seed))
         eng.load_state(st)
