@@ -59,7 +59,11 @@ template <int NKT>
 struct FwdCfg {
     // long sequences: 16 queries per wave and round (the score registers halve, two 8-wave workgroups
     // fit a CU and cover each other's load phases); short ones: 32 queries per wave
+#ifdef GV_LAB_ATTN_QT2       // lab: 32 queries per wave at every length (half the K / V fragment reads per query, one workgroup per CU)
+    static constexpr int QT = 2;
+#else
     static constexpr int QT = NKT >= 14 ? 1 : 2;                  // 16-query tiles per wave and round
+#endif
     static constexpr int NQB = (NKT + QT - 1) / QT;               // query blocks of 16 QT rows
     static constexpr int NW = NQB >= 5 ? 8 : 4;                   // waves per workgroup
     static constexpr int PAIRS = NQB >= NW ? 1 : (NW / NQB >= 1 ? NW / NQB : 1);

@@ -92,6 +92,9 @@ def crop_resize(tiles_u8: torch.Tensor, boxes: torch.Tensor, out_size: int, out:
     return out
 
 
+_VIEW_PARAMS_BYTES = __import__("ctypes").sizeof(L.gv_view_params)      # one packed gv_view_params record
+
+
 def crop_augment(tiles_u8: torch.Tensor, boxes: torch.Tensor, params: torch.Tensor, stats: torch.Tensor, out_size: int,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """DINO views in one pass: the random-resized crop of ``crop_resize`` with each crop's ColorJitter / grayscale / 3x3 blur /
@@ -101,7 +104,7 @@ def crop_augment(tiles_u8: torch.Tensor, boxes: torch.Tensor, params: torch.Tens
     assert tiles_u8.dim() == 4 and tiles_u8.shape[-1] == 3 and tiles_u8.is_contiguous()
     assert boxes.dtype == torch.int32 and boxes.dim() == 2 and boxes.shape[1] == 6 and boxes.is_contiguous() and boxes.device == tiles_u8.device
     n = boxes.shape[0]
-    assert params.dtype == torch.uint8 and params.numel() == n * C_sizeof_view() and params.device == tiles_u8.device
+    assert params.dtype == torch.uint8 and params.numel() == n * _VIEW_PARAMS_BYTES and params.device == tiles_u8.device
     assert stats.dtype == torch.int64 and stats.numel() >= n and stats.device == tiles_u8.device
     if out is None:
         out = torch.empty(n, out_size, out_size, 3, dtype=torch.uint8, device=tiles_u8.device)
@@ -109,11 +112,6 @@ def crop_augment(tiles_u8: torch.Tensor, boxes: torch.Tensor, params: torch.Tens
                                tiles_u8.shape[1], tiles_u8.shape[2], out_size)
     L.call("gv_crop_augment", a, _stream())
     return out
-
-
-def C_sizeof_view() -> int:
-    import ctypes
-    return ctypes.sizeof(L.gv_view_params)
 
 
 def layernorm_fwd(x, gamma, beta, rows: int, D: int, x_stride: Optional[int] = None, eps: float = 1e-6,
