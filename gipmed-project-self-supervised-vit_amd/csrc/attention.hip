@@ -15,6 +15,7 @@
 //           operands of dV^T += dO^T P and dK^T += Q^T dS, so dK/dV need no cross-wave
 //           sum.  Only dS crosses LDS (transposed image) for dQ = dS K.
 #include "gv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -50,6 +51,10 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) { return __builtin_
 __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
     return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
 }
+template <int LO, int HI, class F>
+__device__ __forceinline__ void attn_static_for(F&& f) {
+    if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); attn_static_for<LO + 1, HI>(f); }
+}
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // ---------------------------------------------------------------------------------
@@ -71,22 +76,21 @@ struct FwdCfg {
     static constexpr int ROUNDS = (NQB + WPP - 1) / WPP;          // query blocks per wave
 };
 
+// One workgroup's worth of forward work: `block` = index among the workgroups of this length class, `wave` = wave index inside
+// the NW waves that run it, `smem` = their LDS.  (A stand-alone launch passes blockIdx.x and the whole workgroup; the varlen
+// launch runs two 4-wave instances of the short class side by side in one 8-wave workgroup.)
 template <int NKT>
-__global__ __launch_bounds__(FwdCfg<NKT>::NW * 64, FwdCfg<NKT>::QT == 1 ? 2 : 1) void attn_fwd_kernel(gv_attention_fwd_args a, int n_pairs) {
+__device__ __forceinline__ void attn_fwd_body(const gv_attention_fwd_args a, const int n_pairs, const int block, const int wave, const int lane, GV_LDS char* const smem) {
     using F = FwdCfg<NKT>;
     constexpr int NQB = F::NQB, PAIRS = F::PAIRS, WPP = F::WPP, NW = F::NW, ROUNDS = F::ROUNDS, QT = F::QT, QB = 16 * QT;
     constexpr int NP = NKT * 16;
     constexpr int IMG = NP * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    GV_LDS char* smem = (GV_LDS char*)smem_raw;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = a.N, H = a.H;
     const long ld = 3L * H * 64;
     const bf16* qkv = (const bf16*)a.qkv;
 
     for (int pr = 0; pr < PAIRS; ++pr) {
-        int pair = blockIdx.x * PAIRS + pr;
+        int pair = block * PAIRS + pr;
         pair = pair < n_pairs ? pair : n_pairs - 1;
         const int img = pair / H, h = pair - img * H;
         const bf16* base = qkv + (long)img * N * ld + h * 64;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64, FwdCfg<NKT>::QT == 1 ? 2 : 1)
         stage_rows(base + 2 * H * 64, ld, N, NP, smem + (pr * 2 + 1) * IMG, wave, NW, lane);
     }
     const int lp = wave / WPP, wq = wave % WPP;
-    const int pair_raw = blockIdx.x * PAIRS + lp;
+    const int pair_raw = block * PAIRS + lp;
     const bool valid = pair_raw < n_pairs;
     const int pair = valid ? pair_raw : n_pairs - 1;
     const int img = pair / H, h = pair - img * H;
@@ -121,10 +125,12 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64, FwdCfg<NKT>::QT == 1 ? 2 : 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-#pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) {
+    // (rounds unrolled by hand: left to `#pragma unroll` + break, the loop survives whenever this body is inlined into a second
+    //  kernel, and the register allocation of the N = 197 class jumps from 112 to 227)
+    auto round = [&](auto RDc) {
+        constexpr int rd = decltype(RDc)::value;
         const int qb = wq + rd * WPP;
-        if (qb >= NQB || qb * QB >= N) break;
+        if (qb >= NQB || qb * QB >= N) return;
         f32x4 s[NKT][QT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -210,6 +216,35 @@ __global__ __launch_bounds__(FwdCfg<NKT>::NW * 64, FwdCfg<NKT>::QT == 1 ? 2 : 1)
                 }
             }
         }
+    };
+    attn_static_for<0, ROUNDS>(round);
+}
+
+// (second launch-bounds argument = waves per SIMD the register allocation must leave room for: two 8-wave workgroups per CU = 4)
+template <int NKT>
+__global__ __launch_bounds__(FwdCfg<NKT>::NW * 64, FwdCfg<NKT>::QT == 1 && NKT <= 14 ? 4 : (FwdCfg<NKT>::QT == 1 ? 2 : 1)) void attn_fwd_kernel(gv_attention_fwd_args a, int n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    attn_fwd_body<NKT>(a, n_pairs, blockIdx.x, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, (GV_LDS char*)smem_raw);
+}
+
+// Varlen forward: the token-concatenated row space of a multi-crop pass holds a long segment (N <= 224) and a short one
+// (N <= 64) -- ONE launch serves both: workgroups [0, nblk_long) run the long class (one pair, 8 waves), the rest run TWO
+// short-class instances side by side (waves 0-3 and 4-7, two pairs each, their own LDS halves).  64 KB of LDS and <= 128
+// registers either way: two workgroups per CU.  For the step's student pass (768 long + 3 072 short pairs) that is 768 + 768
+// workgroups = exactly three rounds of the 512 slots, where the long launch alone filled one and a half.
+// (Every instance passes the same workgroup barriers: the bodies' barrier count does not depend on the data.)
+constexpr int VL_LDS_LONG = FwdCfg<14>::PAIRS * 2 * 14 * 16 * 128, VL_LDS_SHORT = FwdCfg<4>::PAIRS * 2 * 4 * 16 * 128;
+constexpr int VL_LDS = VL_LDS_LONG > 2 * VL_LDS_SHORT ? VL_LDS_LONG : 2 * VL_LDS_SHORT;
+static_assert(FwdCfg<14>::NW == 8 && FwdCfg<4>::NW == 4, "varlen launch: 8-wave long class, two 4-wave short instances");
+__global__ __launch_bounds__(512, 4) void attn_fwd_varlen_kernel(gv_attention_fwd_args al, int np_long, int nblk_long, gv_attention_fwd_args as, int np_short) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GV_LDS char* smem = (GV_LDS char*)smem_raw;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if ((int)blockIdx.x < nblk_long) {
+        attn_fwd_body<14>(al, np_long, blockIdx.x, wave, lane, smem);
+    } else {
+        const int sub = wave >> 2;
+        attn_fwd_body<4>(as, np_short, ((int)blockIdx.x - nblk_long) * 2 + sub, wave & 3, lane, smem + sub * VL_LDS_SHORT);
     }
 }
 
@@ -483,18 +518,55 @@ template <int NKT, int KT> int launch_bwd(const gv_attention_bwd_args* a, hipStr
     return GV_OK;
 }
 
-}  // namespace
-
-extern "C" int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream) {
-    GV_REQUIRE(a && a->qkv && a->o && a->lse, GV_E_NULL, "gv_attention_fwd: null pointer");
-    GV_REQUIRE(a->n_img > 0 && a->H > 0 && a->N > 0 && a->N <= 288, GV_E_SHAPE, "gv_attention_fwd: need 0 < N <= 288 (got %d)", a->N);
-    GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16), GV_E_ALIGN, "gv_attention_fwd: qkv/o must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
+int launch_fwd_any(const gv_attention_fwd_args* a, hipStream_t s) {
     if (a->N <= 32) return launch_fwd<2>(a, s);
     if (a->N <= 64) return launch_fwd<4>(a, s);
     if (a->N <= 128) return launch_fwd<8>(a, s);
     if (a->N <= 224) return launch_fwd<14>(a, s);
     return launch_fwd<18>(a, s);
+}
+
+}  // namespace
+
+extern "C" int gv_attention_fwd_varlen(const gv_attention_fwd_varlen_args* v, void* stream) {
+    GV_REQUIRE(v && v->qkv && v->o, GV_E_NULL, "gv_attention_fwd_varlen: null pointer");
+    GV_REQUIRE(v->n_seg >= 1 && v->n_seg <= GV_ATTN_MAX_SEG && v->H > 0, GV_E_SHAPE, "gv_attention_fwd_varlen: 1..%d segments, H > 0", GV_ATTN_MAX_SEG);
+    GV_REQUIRE(gv_aligned(v->qkv, 16) && gv_aligned(v->o, 16), GV_E_ALIGN, "gv_attention_fwd_varlen: qkv/o must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    gv_attention_fwd_args seg[GV_ATTN_MAX_SEG];
+    long row = 0;
+    for (int i = 0; i < v->n_seg; ++i) {
+        GV_REQUIRE(v->n_img[i] > 0 && v->N[i] > 0 && v->N[i] <= 288 && v->lse[i], GV_E_SHAPE, "gv_attention_fwd_varlen: segment %d: need n_img > 0, 0 < N <= 288, lse", i);
+        seg[i].qkv = (const char*)v->qkv + row * 3 * v->H * 64 * 2;
+        seg[i].o = (char*)v->o + row * v->H * 64 * 2;
+        seg[i].lse = v->lse[i]; seg[i].n_img = v->n_img[i]; seg[i].N = v->N[i]; seg[i].H = v->H; seg[i].scale = v->scale;
+        row += (long)v->n_img[i] * v->N[i];
+    }
+    // one launch for a long + a short segment (either order); any other mix runs one launch per segment
+    if (v->n_seg == 2) {
+        const int il = (seg[0].N > 128 && seg[0].N <= 224) ? 0 : ((seg[1].N > 128 && seg[1].N <= 224) ? 1 : -1);
+        const int is = il < 0 ? -1 : 1 - il;
+        if (il >= 0 && seg[is].N > 32 && seg[is].N <= 64) {
+            static GvLdsOptIn opt_in;
+            if (int rc = gv_lds_opt_in(opt_in, (const void*)attn_fwd_varlen_kernel, VL_LDS, "gv_attention_fwd_varlen")) return rc;
+            const int np_long = seg[il].n_img * v->H, np_short = seg[is].n_img * v->H;
+            const int nblk_long = (np_long + FwdCfg<14>::PAIRS - 1) / FwdCfg<14>::PAIRS;
+            const int nblk_short = (np_short + 2 * FwdCfg<4>::PAIRS - 1) / (2 * FwdCfg<4>::PAIRS);
+            hipLaunchKernelGGL(attn_fwd_varlen_kernel, dim3(nblk_long + nblk_short), dim3(512), VL_LDS, s, seg[il], np_long, nblk_long, seg[is], np_short);
+            GV_LAUNCH_CHECK("gv_attention_fwd_varlen");
+            return GV_OK;
+        }
+    }
+    for (int i = 0; i < v->n_seg; ++i)
+        if (int rc = launch_fwd_any(&seg[i], s)) return rc;
+    return GV_OK;
+}
+
+extern "C" int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->qkv && a->o && a->lse, GV_E_NULL, "gv_attention_fwd: null pointer");
+    GV_REQUIRE(a->n_img > 0 && a->H > 0 && a->N > 0 && a->N <= 288, GV_E_SHAPE, "gv_attention_fwd: need 0 < N <= 288 (got %d)", a->N);
+    GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16), GV_E_ALIGN, "gv_attention_fwd: qkv/o must be 16-byte aligned");
+    return launch_fwd_any(a, (hipStream_t)stream);
 }
 
 extern "C" int gv_attention_bwd(const gv_attention_bwd_args* a, void* stream) {

@@ -329,8 +329,13 @@ class VitRunner:
             if not fused or i == 0:
                 ops.layernorm_fwd(xa, W.f(b + "norm1.weight"), W.f(b + "norm1.bias"), T, D, y=G.xn1[s], mean=st[0], rstd=st[1])
             ops.linear(G.xn1[s], W.w(b + "attn.qkv.weight"), G.qkv[s], T, 3 * D, D, epilogue=E.EPI_BIAS, bias=W.f(b + "attn.qkv.bias"))
-            for sg in G.segs:
-                ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s])
+            if len(G.segs) > 1 and os.environ.get("GIPVIT_VARLEN_ATTN", "1") != "0":
+                # the crop lengths of a multi-crop pass in ONE call (gv_attention_fwd_varlen: the 37-token pairs fill the 197-token
+                # launch's half-empty last round); GIPVIT_VARLEN_ATTN=0 keeps one launch per segment for A/B runs
+                ops.attention_fwd_varlen(G.qkv[s], G.o[s], [(sg.n_img, sg.N, sg.lse[s]) for sg in G.segs], H, self.scale)
+            else:
+                for sg in G.segs:
+                    ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s])
             if fused:
                 ops.linear_ln_fwd(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, bias=W.f(b + "attn.proj.bias"), resid=xa,
                                   gamma=W.f(b + "norm2.weight"), beta=W.f(b + "norm2.bias"), y=G.xn2[s], mean=st[2], rstd=st[3], row_scale=rs_a)

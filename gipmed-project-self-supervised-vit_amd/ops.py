@@ -238,6 +238,29 @@ def attention_fwd(qkv, n_img: int, N: int, H: int, scale: float, o=None, lse=Non
     return o, lse
 
 
+def attention_fwd_varlen(qkv, o, segments, H: int, scale: float):
+    """All segments of a token-concatenated row space in one call: ``segments`` = [(n_img, N, lse f32 [n_img, H, N]), ...] in row
+    order; qkv [T, 3 H 64], o [T, H 64].  bf16: gv_attention_fwd_varlen (a long + a short segment share ONE launch); the fp32
+    operand mode runs one call per segment."""
+    if qkv.dtype != torch.bfloat16 or len(segments) > L.GV_ATTN_MAX_SEG:
+        row = 0
+        for n_img, N, lse in segments:
+            attention_fwd(qkv[row:row + n_img * N], n_img, N, H, scale, o=o[row:row + n_img * N], lse=lse)
+            row += n_img * N
+        return
+    if o.dtype != qkv.dtype:
+        raise TypeError(f"attention_fwd_varlen: qkv is {qkv.dtype} but o is {o.dtype}")
+    a = L.gv_attention_fwd_varlen_args()
+    a.qkv, a.o, a.n_seg, a.H, a.scale = qkv.data_ptr(), o.data_ptr(), len(segments), H, scale
+    rows = 0
+    for i, (n_img, N, lse) in enumerate(segments):
+        assert lse.dtype == f32 and lse.numel() >= n_img * H * N
+        a.n_img[i], a.N[i], a.lse[i] = n_img, N, lse.data_ptr()
+        rows += n_img * N
+    assert qkv.shape[0] >= rows and o.shape[0] >= rows and qkv.is_contiguous() and o.is_contiguous()
+    L.call("gv_attention_fwd_varlen", a, _stream())
+
+
 def attention_bwd(qkv, o, d_o, lse, n_img: int, N: int, H: int, scale: float, dqkv=None):
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
     a = L.gv_attention_bwd_args(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), n_img, N, H, scale)

@@ -345,6 +345,20 @@ typedef struct {
 } gv_attention_fwd_args;
 int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream);
 
+/* Varlen forward (the `cu_seqlens` form): the token-concatenated row space of a multi-crop pass -- segment i
+ * holds n_img[i] images of N[i] tokens, its rows start where segment i - 1 ends, qkv / o cover all segments, lse[i] is
+ * segment i's f32 [n_img[i], H, N[i]].  A long (128 < N <= 224) + a short (32 < N <= 64) segment run as ONE launch
+ * (the short pairs fill the long launch's last, half-empty round of workgroups); any other mix runs one launch per segment.
+ * (The backward stays one call per segment: its long class holds a CU's LDS alone, so a merged launch gains nothing.)       */
+#define GV_ATTN_MAX_SEG 4
+typedef struct {
+    const void* qkv; void* o;
+    int32_t n_seg; int32_t n_img[GV_ATTN_MAX_SEG]; int32_t N[GV_ATTN_MAX_SEG];
+    float* lse[GV_ATTN_MAX_SEG];
+    int32_t H; float scale;
+} gv_attention_fwd_varlen_args;
+int gv_attention_fwd_varlen(const gv_attention_fwd_varlen_args* a, void* stream);
+
 typedef struct {
     const void* qkv; const void* o; const void* d_o; const float* lse;
     void* dqkv;           /* bf16 [n_img*N, 3, H, 64]                        */

@@ -572,6 +572,31 @@ def test_adamw_ema(dev):
         close(p3, pr.detach(), 1e-5, 1e-6, f"optimizer mode {mode}")
 
 
+@pytest.mark.parametrize("segs", [[(6, 197), (20, 37)], [(9, 37), (3, 197)], [(130, 197), (530, 37)], [(4, 100), (5, 37)], [(3, 197)], [(2, 224), (7, 64), (3, 17)]])
+def test_attention_fwd_varlen(dev, segs):
+    """gv_attention_fwd_varlen: the segments of a token-concatenated row space (multi-crop: 197- and 37-token crops) in one call.  A
+    long + a short segment run as ONE launch (two short instances per workgroup fill the long launch's last round); every other
+    mix runs per segment.  Either way the result equals the per-segment calls bit for bit, and rows outside are untouched."""
+    o, H = ops(), 6
+    g = torch.Generator().manual_seed(17)
+    T = sum(n * N for n, N in segs)
+    qkv = torch.randn(T + 3, 3 * H * 64, generator=g).to(dev).to(bf16)
+    out = torch.full((T + 3, H * 64), 7.0, dtype=bf16, device=dev)
+    lses = [torch.empty(n, H, N, dtype=f32, device=dev) for n, N in segs]
+    o.attention_fwd_varlen(qkv, out, [(n, N, l) for (n, N), l in zip(segs, lses)], H, 0.125)
+    row = 0
+    for (n, N), l in zip(segs, lses):
+        ref_o, ref_l = o.attention_fwd(qkv[row:row + n * N], n, N, H, 0.125)
+        assert torch.equal(out[row:row + n * N], ref_o) and torch.equal(l, ref_l), (n, N)
+        row += n * N
+    assert float(out[T:].float().min()) == 7.0
+    # ... and against fp32 torch on the first segment
+    n, N = segs[0]
+    q, k, v = (qkv[:n * N].float().view(n, N, 3, H, 64)[:, :, i].transpose(1, 2) for i in range(3))
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(n * N, H * 64)
+    close(out[:n * N], ref, 2e-2, 2e-2, "varlen vs sdpa")
+
+
 def test_lamb_matches_oracle(dev):
     """gv_lamb (timm --opt lamb: global-norm pre-clip, Adam moments, per-tensor trust ratio on the decayed tensors, EMA copy) against
     the oracle's restatement over an arena of three tensors, three steps."""
