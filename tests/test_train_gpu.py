@@ -167,6 +167,31 @@ def test_train_dino_drop_path(dev, tmp_path):
 
 
 @pytest.mark.gpu
+def test_train_opt_values_select_their_own_arithmetic(dev, tmp_path):
+    """Every accepted --opt value (and --clip-mode value) through the driver: sgd / adam / adamw / lamb runs from one seed end at
+    different weights (nothing is mapped onto a neighbour), lamb resumes with its moments, an unsupported value exits before any GPU work."""
+    sys.path.insert(0, ROOT)
+    import train
+    base = ["--model", "vit_tiny", "--dataset", "synthetic", "--num-classes", "2", "--img-size", "64", "--tile-size", "64", "-b", "8",
+            "--batches-per-epoch", "4", "--epochs", "1", "--lr", "1e-3", "--warmup-epochs", "0", "--weight-decay", "0.05", "--log-interval", "2",
+            "--output", str(tmp_path), "--seed", "3", "--no-validate", "--clip-grad", "0.5"]
+    ends = {}
+    for name, extra in (("sgd", ["--opt", "sgd"]), ("adam", ["--opt", "adam"]), ("adamw", ["--opt", "adamw"]), ("lamb", ["--opt", "lamb"]),
+                        ("adamw_val", ["--opt", "adamw", "--clip-mode", "value"])):
+        assert train.main(base + ["--experiment", name] + extra) == 0
+        ck = torch.load(tmp_path / name / "last.pth.tar", weights_only=True)
+        ends[name] = ck["state_dict"]["blocks.5.mlp.fc1.weight"]
+        assert torch.isfinite(ends[name]).all() and ck["optimizer"]["step"] == 4
+    names = list(ends)
+    for i in range(len(names)):
+        for j in range(i + 1, len(names)):
+            assert _rel(ends[names[i]], ends[names[j]]) > 1e-5, (names[i], names[j])
+    assert train.main(base + ["--experiment", "lamb", "--opt", "lamb", "--epochs", "2", "--resume", str(tmp_path / "lamb" / "last.pth.tar")]) == 0
+    with pytest.raises(SystemExit):
+        train.main(base + ["--experiment", "bad", "--opt", "nadam"])
+
+
+@pytest.mark.gpu
 def test_train_dino_view_augment(dev, tmp_path):
     """--random-crops --view-augment through the driver: every crop is cut and augmented (colour jitter / grayscale / blur /
     solarise with its own draws) in one device pass; the run trains, is reproducible from its seed and differs from the
