@@ -724,10 +724,15 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 
 // rows per workgroup for M rows: the smallest supported FM that covers M in as few full rounds of 256 workgroups as possible
 constexpr int FM_SET8[] = {4, 7, 9, 11, 12};
+#ifdef GV_LAB_CU_BUDGET      // lab: size the launches for a share of the chip (two half-batch steps side by side, tools/concurrent_micro.py)
+int cu_budget() { static const int b = [] { const char* e = getenv("GIPVIT_CU_BUDGET"); return e ? atoi(e) : 256; }(); return b; }
+#else
+constexpr int cu_budget() { return 256; }
+#endif
 int pick_fm(int M) {
     const int m16 = (M + 15) / 16;
-    const int rounds = (m16 + 256 * 12 - 1) / (256 * 12);
-    const int need = (m16 + 256 * rounds - 1) / (256 * rounds);
+    const int rounds = (m16 + cu_budget() * 12 - 1) / (cu_budget() * 12);
+    const int need = (m16 + cu_budget() * rounds - 1) / (cu_budget() * rounds);
     for (int fm : FM_SET8) if (fm >= need) return fm;
     return 12;
 }
@@ -742,7 +747,7 @@ int wide_grid(int M, int BM, int ncb) {
 }
 // ... and the smallest supported FM whose launch is one round of workgroups (<= 256); 12 (several rounds) for larger M
 int pick_fm_wide(int M, int ncb) {
-    for (int fm : FM_SET8) if (wide_grid(M, 16 * fm, ncb) <= 256) return fm;
+    for (int fm : FM_SET8) if (wide_grid(M, 16 * fm, ncb) <= cu_budget()) return fm;
     return 12;
 }
 

@@ -33,10 +33,11 @@ def run(engs, steps=20, warm=5):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps
 
-big = [make(N * B)]
-dt = run(big)
-print(f"one engine  B={N * B}: {dt * 1e3:.2f} ms/step  {N * B / dt:.0f} tiles/s", flush=True)
-del big; torch.cuda.empty_cache()
+if not os.environ.get("GIPVIT_CU_BUDGET"):
+    big = [make(N * B)]
+    dt = run(big)
+    print(f"one engine  B={N * B}: {dt * 1e3:.2f} ms/step  {N * B / dt:.0f} tiles/s", flush=True)
+    del big; torch.cuda.empty_cache()
 two = [make(B) for _ in range(N)]
 dt = run(two)
 print(f"{N} engines   B={B} each, concurrent: {dt * 1e3:.2f} ms/step  {N * B / dt:.0f} tiles/s", flush=True)
