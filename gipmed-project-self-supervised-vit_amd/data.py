@@ -89,6 +89,25 @@ class SyntheticTiles:
             yield first if self.fixed else (first if i == 0 else self._batch(g))
         self.epoch += 1
 
+    # ---- device path (DevicePrefetcher): the same distribution drawn ON the GPU, straight into the device slot.  Drawing
+    # 12.6 M normals per batch on the host took 0.18 s -- train.py --dataset synthetic ran at 320 tiles/s next to bench.py's 4 700.
+    def start_epoch_device(self, device):
+        self._gdev = torch.Generator(device=device).manual_seed(self.seed + (0 if self.fixed else 1000 * self.epoch))
+        self._first_dev = None
+        self.epoch += 1
+
+    def fill_device(self, data: torch.Tensor, target: torch.Tensor):
+        """Write the next batch into ``data`` u8 [B, size, size, 3] / ``target`` i64 [B, 1] (device tensors) on the current stream."""
+        if self.fixed and self._first_dev is not None:
+            data.copy_(self._first_dev[0]); target.copy_(self._first_dev[1])
+            return
+        x = torch.randn(data.shape, device=data.device, generator=self._gdev)
+        x.mul_(self.std.to(data.device)).add_(self.mean.to(data.device)).round_().clamp_(0, 255)
+        data.copy_(x)
+        target.copy_(torch.randint(0, self.C, target.shape, device=data.device, generator=self._gdev))
+        if self.fixed:
+            self._first_dev = (data.clone(), target.clone())
+
 
 # --------------------------------------------------------------------------- #
 # slide folders
@@ -363,7 +382,11 @@ class DevicePrefetcher:
     def _submit(self, k: int, it) -> bool:
         """Start filling pinned slot k with the next batch (reader threads); False at the end of the epoch."""
         self._futs[k] = []
-        if hasattr(self.src, "fill"):
+        if self._on_device:                       # the source draws its batch on the GPU (_h2d): nothing to stage on the host
+            if self._left == 0:
+                return False
+            self._left -= 1
+        elif hasattr(self.src, "fill"):
             if self._left == 0:
                 return False
             self._left -= 1
@@ -388,8 +411,11 @@ class DevicePrefetcher:
         if self.freed[k] is not None:
             self.copy.wait_event(self.freed[k])                   # the step that read device slot k has finished
         with torch.cuda.stream(self.copy):
-            self.dbuf[k].copy_(self.pin[k], non_blocking=True)
-            self.dtgt[k].copy_(self.pin_t[k], non_blocking=True)
+            if self._on_device:
+                self.src.fill_device(self.dbuf[k], self.dtgt[k])
+            else:
+                self.dbuf[k].copy_(self.pin[k], non_blocking=True)
+                self.dtgt[k].copy_(self.pin_t[k], non_blocking=True)
             if self.aug is not None:
                 self.d_a[k].copy_(self.pin_a[k], non_blocking=True)
                 if self.has_fill[k]:
@@ -399,7 +425,11 @@ class DevicePrefetcher:
     def __iter__(self):
         it = None
         self._futs = [[], []]
-        if hasattr(self.src, "fill"):
+        self._on_device = hasattr(self.src, "fill_device") and self.dev.type == "cuda"
+        if self._on_device:
+            self.src.start_epoch_device(self.dev)
+            self._left = len(self.src)
+        elif hasattr(self.src, "fill"):
             self.src._start_epoch()
             self._left = len(self.src)
         else:
