@@ -58,6 +58,21 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
     }
 }
 
+// adaptive gradient clipping: one wave per unit (include/gipvit.h gv_agc)
+__global__ __launch_bounds__(256) void agc_kernel(gv_agc_args a) {
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= a.n_units) return;
+    const int off = a.units[2 * u], len = a.units[2 * u + 1];
+    const float* p = a.p + off; float* g = a.grad + off;
+    float sp = 0.f, sg = 0.f;
+    for (int i = lane; i < len; i += 64) { const float pv = p[i], gv = g[i] * a.grad_scale; sp += pv * pv; sg += gv * gv; }
+    sp = wave_sum(sp); sg = wave_sum(sg);
+    const float max_norm = fmaxf(sqrtf(sp), a.eps) * a.clip_factor, gn = sqrtf(sg);
+    if (gn < max_norm) return;
+    const float c = max_norm / fmaxf(gn, 1e-6f);
+    for (int i = lane; i < len; i += 64) g[i] *= c;
+}
+
 // LAMB, both phases (include/gipvit.h gv_lamb).  One workgroup per table entry: a slice of ONE tensor.
 __global__ __launch_bounds__(256) void lamb_kernel(gv_lamb_args a) {
     const int tensor = a.blocks[blockIdx.x * 3], lo = a.blocks[blockIdx.x * 3 + 1], hi = a.blocks[blockIdx.x * 3 + 2];
@@ -113,6 +128,14 @@ __global__ __launch_bounds__(256) void lamb_kernel(gv_lamb_args a) {
 }
 
 }  // namespace
+
+extern "C" int gv_agc(const gv_agc_args* a, void* stream) {
+    GV_REQUIRE(a && a->p && a->grad && a->units, GV_E_NULL, "gv_agc: null pointer");
+    GV_REQUIRE(a->n_units > 0 && a->clip_factor > 0.f && a->eps > 0.f, GV_E_SHAPE, "gv_agc: need n_units > 0, clip_factor > 0, eps > 0");
+    hipLaunchKernelGGL(agc_kernel, dim3((a->n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_agc");
+    return GV_OK;
+}
 
 extern "C" int gv_lamb(const gv_lamb_args* a, void* stream) {
     GV_REQUIRE(a && a->p && a->grad && a->m && a->v && a->blocks && a->stats && a->gnorm_sq, GV_E_NULL, "gv_lamb: null pointer");

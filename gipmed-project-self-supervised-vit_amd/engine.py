@@ -919,8 +919,8 @@ class SupervisedEngine:
         of SURVEY 8d are stated for; an order of magnitude slower, kept for verification)."""
         if precision not in ("bf16", "fp32"):
             raise ValueError(f"precision {precision!r}: 'bf16' or 'fp32'")
-        if clip_mode not in ("norm", "value"):
-            raise ValueError(f"clip_mode {clip_mode!r}: 'norm' or 'value' (train.py:1072-1077; 'agc' is not built)")
+        if clip_mode not in ("norm", "value", "agc"):
+            raise ValueError(f"clip_mode {clip_mode!r}: 'norm', 'value' or 'agc' (train.py:1072-1077)")
         if clip_mode == "value" and opt == "lamb":
             raise ValueError("--clip-mode value with --opt lamb is not built (Lamb's own global-norm clip needs the norm of the clamped gradient)")
         self.clip_mode = clip_mode
@@ -956,6 +956,10 @@ class SupervisedEngine:
         self.opt_mode = {"adamw": 0, "adam": 1, "sgd": 2, "lamb": -1}[opt]
         if opt == "sgd":
             self.betas = (momentum, betas[1])
+        if clip_mode == "agc" and clip_grad > 0:
+            # adaptive gradient clipping (timm adaptive_clip_grad; the reference excludes the classifier: model_parameters(exclude_head=True))
+            a = self.arena
+            self._agc_units = ops.agc_units([(a.off[n], a.specs[n]) for n in a.order if not n.startswith("head.")]).to(dev)
         if opt == "lamb":
             # timm.optim.Lamb (reference train.py:161, 583): per-tensor trust ratio -> every tensor's norms are needed before its
             # update: two launches per arena segment over a block table that never crosses a tensor (gv_lamb)
@@ -1018,6 +1022,8 @@ class SupervisedEngine:
         a = self.arena
         self.t += 1
         by_norm = self.clip > 0 and self.clip_mode == "norm"
+        if self.clip > 0 and self.clip_mode == "agc":
+            ops.agc(a.p, a.g, self._agc_units, self.clip, 1e-3, 1.0 / self.reducer.world)
         if by_norm:
             ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
         kw = dict(lr=self.lr if lr is None else lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=self.t,

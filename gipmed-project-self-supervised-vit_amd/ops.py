@@ -375,3 +375,25 @@ def lamb(p, grad, m, v, p_bf16, teacher, teacher_bf16, blocks, stats, gnorm_sq, 
                        blocks.shape[0], stats.data_ptr(), lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
                        grad_scale, clip_norm, max_grad_norm, gnorm_sq.data_ptr(), teacher_momentum, phase)
     L.call("gv_lamb", a, _stream())
+
+
+def agc_units(tensors) -> torch.Tensor:
+    """Unit table of gv_agc for tensors = [(offset, shape), ...]: one unit per index of dim 0 (timm unitwise_norm: the norm over all
+    other dims), the whole tensor for 1-D parameters; int32 [n_units, 2] = (offset, length)."""
+    rows = []
+    for off, shape in tensors:
+        n = 1
+        for d in shape:
+            n *= d
+        if len(shape) <= 1:
+            rows.append((off, n))
+        else:
+            per = n // shape[0]
+            rows.extend((off + r * per, per) for r in range(shape[0]))
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+def agc(p, grad, units, clip_factor: float, eps: float = 1e-3, grad_scale: float = 1.0):
+    """Adaptive gradient clipping in place on ``grad`` (units: device int32 [n, 2] from agc_units); see gv_agc."""
+    assert units.dtype == torch.int32 and units.is_contiguous() and units.device == grad.device
+    L.call("gv_agc", L.gv_agc_args(p.data_ptr(), grad.data_ptr(), units.data_ptr(), units.shape[0], clip_factor, eps, grad_scale), _stream())

@@ -488,6 +488,17 @@ typedef struct {
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
 
+/* ---- adaptive gradient clipping (`--clip-mode agc`, reference train.py:1072-1077 -> timm.utils.adaptive_clip_grad): per UNIT
+ * (a row of a matrix / conv filter = dim 0 of the parameter; a whole tensor for 1-D parameters and for tensors whose dim 0 is 1)
+ *   g_u <- g_u * min(1, clip_factor * max(||p_u||, eps) / max(||g_u||, 1e-6)),   g_u = grad_u * grad_scale for the norms
+ * in place on the (unscaled) gradient arena, before the optimizer pass.  units: device int32 [n_units][2] = {offset, length}
+ * into p / grad (offsets multiples of 4 are not required).  One wave per unit.                                            */
+typedef struct {
+    const float* p; float* grad; const int32_t* units; int32_t n_units;
+    float clip_factor, eps, grad_scale;
+} gv_agc_args;
+int gv_agc(const gv_agc_args* a, void* stream);
+
 /* ---- LAMB (timm `--opt lamb`, reference train.py:161 -> create_optimizer_v2 -> timm.optim.Lamb; named in SURVEY 8f-4) over the
  * same flat arena, two launches per range (a per-TENSOR trust ratio needs every tensor's norms before its update):
  *   phase 0:  g = grad * grad_scale * c, c = the global-norm clips (clip_norm as in gv_adamw_ema, then Lamb's own

@@ -376,3 +376,20 @@ class Lamb:
                 wn, un = float(p.norm()), float(upd.norm())
                 upd = upd * (wn / un if wn > 0 and un > 0 else 1.0)
             p.add_(upd, alpha=-lr)
+
+
+def adaptive_clip_grad(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], clip_factor: float, eps: float = 1e-3, skip=()):
+    """timm.utils.adaptive_clip_grad restated (reference train.py:1072-1077 `--clip-mode agc`; timm is not importable here: follows
+    the published algorithm, unpinned beyond this restatement): per unit (index of dim 0; the whole tensor for 1-D parameters)
+    g <- g * max_norm / max(||g||, 1e-6) where ||g|| >= max_norm = clip_factor * max(||p||, eps).  Returns new gradients."""
+    def unit_norm(x):
+        return x.norm(2) if x.ndim <= 1 else x.norm(2, dim=tuple(range(1, x.ndim)), keepdim=True)
+    out = {}
+    for k, g in grads.items():
+        if g is None or k in skip:
+            out[k] = g
+            continue
+        max_norm = unit_norm(params[k]).clamp(min=eps) * clip_factor
+        gn = unit_norm(g)
+        out[k] = torch.where(gn < max_norm, g, g * (max_norm / gn.clamp(min=1e-6)))
+    return out

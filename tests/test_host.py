@@ -305,7 +305,7 @@ def test_every_used_flag_is_read_by_the_driver():
         elif e["flags"][0] != "data":
             assert reads == 0, f"{e['flags']} is read by train.py but marked used=False"
     # values the build cannot honour are refused before any GPU work
-    for bad in (["--drop", "0.1"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "agc"], ["--clip-mode", "value", "--opt", "lamb"], ["--in-chans", "1"],
+    for bad in (["--drop", "0.1"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "adaptive"], ["--clip-mode", "agc", "--dino"], ["--clip-mode", "value", "--opt", "lamb"], ["--in-chans", "1"],
                 ["--input-size", "3", "224", "200"], ["--dino", "--supervised"], ["--amp", "--amp-dtype", "bfloat16", "--precision", "fp32"],
                 ["--opt", "lars"], ["--opt", "rmsprop"], ["--opt", "nadam"], ["--opt", "momentum"], ["--sched", "tanh"], ["--sched", "plateau"],
                 ["--sched", "multistep"], ["--sched", "poly"], ["--dino", "--opt", "sgd"], ["--dino", "--opt", "adam"], ["--dino", "--opt", "lamb"]):

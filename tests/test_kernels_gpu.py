@@ -597,6 +597,34 @@ def test_attention_fwd_varlen(dev, segs):
     close(out[:n * N], ref, 2e-2, 2e-2, "varlen vs sdpa")
 
 
+def test_agc_matches_oracle(dev):
+    """gv_agc (--clip-mode agc, timm adaptive_clip_grad) against the oracle's restatement: rows of matrices and conv filters, whole 1-D
+    tensors and dim-0-of-one tensors are units; only units whose gradient norm exceeds clip_factor * max(||p||, eps) are rescaled."""
+    import math
+    from oracle import vit_oracle as vo
+    g = torch.Generator().manual_seed(5)
+    shapes = {"w": (37, 50), "conv": (6, 3, 4, 4), "b": (45,), "pos": (1, 7, 12), "tiny": (3, 8)}
+    params = {k: torch.randn(*sh, generator=g) * (1e-5 if k == "tiny" else 0.2) for k, sh in shapes.items()}         # 'tiny': ||p|| < eps
+    grads = {k: torch.randn(*sh, generator=g) * torch.rand(sh[0] if len(sh) > 1 else 1, *([1] * (len(sh) - 1)), generator=g) * 0.5 for k, sh in shapes.items()}
+    ref = vo.adaptive_clip_grad(params, {k: v * 0.5 for k, v in grads.items()}, 0.05)          # the oracle sees the scaled (mean) gradient
+    offs, o_ = {}, 0
+    for k, sh in shapes.items():
+        offs[k] = o_; o_ += (math.prod(sh) + 63) // 64 * 64
+    P, G = torch.zeros(o_), torch.zeros(o_)
+    for k, sh in shapes.items():
+        P[offs[k]:offs[k] + math.prod(sh)] = params[k].reshape(-1); G[offs[k]:offs[k] + math.prod(sh)] = grads[k].reshape(-1)
+    P, G = P.to(dev), G.to(dev)
+    units = ops().agc_units([(offs[k], sh) for k, sh in shapes.items()]).to(dev)
+    assert units.shape[0] == 37 + 6 + 1 + 1 + 3
+    ops().agc(P, G, units, 0.05, 1e-3, grad_scale=0.5)
+    changed = 0
+    for k, sh in shapes.items():
+        got = G[offs[k]:offs[k] + math.prod(sh)].view(sh).cpu() * 0.5
+        close(got, ref[k], 1e-5, 1e-7, f"agc {k}")
+        changed += int((ref[k] != grads[k] * 0.5).any())
+    assert changed >= 3                                             # the case does clip something
+
+
 def test_lamb_matches_oracle(dev):
     """gv_lamb (timm --opt lamb: global-norm pre-clip, Adam moments, per-tensor trust ratio on the decayed tensors, EMA copy) against
     the oracle's restatement over an arena of three tensors, three steps."""

@@ -138,9 +138,11 @@ def check_supported(args, log=_logger.warning):
     if args.pretrained and not args.initial_checkpoint:
         raise SystemExit("--pretrained downloads weights by URL (reference train.py:482-485): there is no network here -- "
                          "pass the file with --initial-checkpoint instead")
-    if args.clip_mode not in ("norm", "value"):
-        raise SystemExit(f"--clip-mode {args.clip_mode}: 'norm' (global norm, the reference default) and 'value' (element-wise clamp) are fused into the "
-                         "optimizer kernel (train.py:1072-1077); 'agc' is not built")
+    if args.clip_mode not in ("norm", "value", "agc"):
+        raise SystemExit(f"--clip-mode {args.clip_mode}: 'norm' (global norm, the reference default), 'value' (element-wise clamp) or 'agc' (adaptive, "
+                         "per unit) -- the three modes of timm's dispatch_clip_grad (train.py:1072-1077)")
+    if args.clip_mode == "agc" and args.dino:
+        raise SystemExit("--clip-mode agc with --dino is not built (the reference applies it to a supervised model minus its classifier)")
     if args.clip_mode == "value" and args.opt.lower() == "lamb":
         raise SystemExit("--clip-mode value with --opt lamb is not built (Lamb's own global-norm clip needs the norm of the clamped gradient)")
     if args.opt.lower() not in SUPPORTED_OPTS:
