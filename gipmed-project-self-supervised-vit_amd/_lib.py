@@ -100,6 +100,10 @@ gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
     ("p", vp), ("grad", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("teacher", vp), ("teacher_bf16", vp), ("n", i64),
     ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bias_corr1", f32), ("bias_corr2", f32),
     ("grad_scale", f32), ("clip_norm", f32), ("gnorm_sq", vp), ("teacher_momentum", f32), ("hyper", vp), ("mode", i32), ("clip_value", f32)])
+u32 = C.c_uint32
+gv_dropout_args = _struct("gv_dropout_args", [("x", vp), ("x_is_f32", i32), ("n", i64), ("seed", u32), ("threshold", u32), ("scale", f32)])
+gv_dropout_add_args = _struct("gv_dropout_add_args", [("t", vp), ("resid", vp), ("out", vp), ("row_scale", vp), ("rows", i32), ("cols", i32),
+                                                      ("seed", u32), ("threshold", u32), ("scale", f32)])
 gv_agc_args = _struct("gv_agc_args", [("p", vp), ("grad", vp), ("units", vp), ("n_units", i32), ("clip_factor", f32), ("eps", f32), ("grad_scale", f32)])
 gv_lamb_args = _struct("gv_lamb_args", [
     ("p", vp), ("grad", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("teacher", vp), ("teacher_bf16", vp), ("blocks", vp), ("n_blocks", i32),
@@ -116,7 +120,7 @@ ENTRY_POINTS = {
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,
     "gv_dino_loss": gv_dino_loss_args, "gv_center_update": gv_center_update_args, "gv_softmax_lsce": gv_softmax_lsce_args,
     "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_store_f32": gv_store_f32_args, "gv_sumsq": gv_sumsq_args,
-    "gv_adamw_ema": gv_adamw_ema_args, "gv_lamb": gv_lamb_args, "gv_agc": gv_agc_args,
+    "gv_adamw_ema": gv_adamw_ema_args, "gv_lamb": gv_lamb_args, "gv_agc": gv_agc_args, "gv_dropout": gv_dropout_args, "gv_dropout_add": gv_dropout_add_args,
     # fp32 operand mode: the same structs with every bf16 buffer read / written as f32
     "gv_linear_f32": gv_linear_args, "gv_attention_fwd_f32": gv_attention_fwd_args, "gv_attention_bwd_f32": gv_attention_bwd_args,
     "gv_layernorm_fwd_f32": gv_layernorm_fwd_args, "gv_layernorm_bwd_f32": gv_layernorm_bwd_args, "gv_patchify_f32": gv_patchify_args,

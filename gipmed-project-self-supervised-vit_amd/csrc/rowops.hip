@@ -360,6 +360,48 @@ extern "C" int gv_cast_bf16(const gv_cast_bf16_args* a, void* stream) {
     return GV_OK;
 }
 
+// ---- dropout (include/gipvit.h gv_dropout / gv_dropout_add): counter-based keep masks
+namespace {
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thr) {
+    uint32_t h = seed + 0x9E3779B9u * (idx + 1u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h >= thr;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(gv_dropout_args a) {
+    T* x = (T*)a.x;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256)
+        x[i] = drop_keep(a.seed, (uint32_t)i, a.threshold) ? (T)((float)x[i] * a.scale) : (T)0.0f;
+}
+__global__ __launch_bounds__(256) void dropout_add_kernel(gv_dropout_add_args a) {
+    const long n = (long)a.rows * a.cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / a.cols);
+        const float v = drop_keep(a.seed, (uint32_t)i, a.threshold) ? a.t[i] * a.scale : 0.0f;
+        a.out[i] = a.resid[i] + (a.row_scale ? a.row_scale[m] : 1.0f) * v;
+    }
+}
+}  // namespace
+
+extern "C" int gv_dropout(const gv_dropout_args* a, void* stream) {
+    GV_REQUIRE(a && a->x, GV_E_NULL, "gv_dropout: null pointer");
+    GV_REQUIRE(a->n > 0 && a->n < (1ll << 32), GV_E_SHAPE, "gv_dropout: need 0 < n < 2^32 elements per site (got %ld)", (long)a->n);
+    long blocks = (a->n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    if (a->x_is_f32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(dropout_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_dropout");
+    return GV_OK;
+}
+
+extern "C" int gv_dropout_add(const gv_dropout_add_args* a, void* stream) {
+    GV_REQUIRE(a && a->t && a->resid && a->out, GV_E_NULL, "gv_dropout_add: null pointer");
+    GV_REQUIRE(a->rows > 0 && a->cols > 0 && (long)a->rows * a->cols < (1ll << 32), GV_E_SHAPE, "gv_dropout_add: need 0 < rows * cols < 2^32");
+    long blocks = ((long)a->rows * a->cols + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_dropout_add");
+    return GV_OK;
+}
+
 extern "C" int gv_sumsq(const gv_sumsq_args* a, void* stream) {
     GV_REQUIRE(a && a->x && a->workspace && a->out, GV_E_NULL, "gv_sumsq: null pointer");
     GV_REQUIRE(a->n > 0 && gv_aligned(a->x, 16), GV_E_ALIGN, "gv_sumsq: x must be 16-byte aligned, n > 0");

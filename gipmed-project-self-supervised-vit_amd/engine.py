@@ -243,6 +243,7 @@ class VitGroup:
             self.dh_b, self.dqkv_b = e((T, 4 * D), act), e((T, 3 * D), act)
 
         self.depth, self.device = depth, device
+        self.dropout, self.tmp = None, None   # --drop: (p, step seed) and the f32 branch-output buffer of the unfused residual adds (set_dropout)
         self.rs = None            # stochastic depth: f32 [depth, 2, T] row factors of the attention / MLP branch (set_drop)
         self.drop_img = None      # ... and the per-image factors they were expanded from
         self._row_img = None
@@ -262,6 +263,22 @@ class VitGroup:
             self._rs_buf = _empty((self.depth, 2, self.T), f32, self.device)
         ops.expand_rows(per_img.contiguous(), self._row_img, self._rs_buf, self.depth * 2, self.n_img, self.T)
         self.rs = self._rs_buf
+
+    def set_dropout(self, p: float, seed: int):
+        """Dropout (--drop, nn.Dropout after the pos-embed add, attn.proj, the MLP activation and mlp.fc2; vit.pyc@L98-131, L235-246) for
+        the next forward / backward of this group: probability ``p`` and this step's 32-bit ``seed`` (the masks are counter-based:
+        the backward regenerates them), or p = 0 to switch it off.  The step then runs the unfused Linear / LayerNorm kernels."""
+        if not p:
+            self.dropout = None
+            return
+        if not 0.0 < p < 1.0:
+            raise ValueError(f"dropout probability {p}: need 0 <= p < 1")
+        assert self.save, "dropout belongs to a training pass"
+        if self.T * 4 * self.x[0].shape[1] >= 1 << 32:
+            raise ValueError("dropout: a site has more than 2^32 elements")
+        self.dropout = (float(p), int(seed) & 0xFFFFFFFF)
+        if self.tmp is None:
+            self.tmp = _empty(tuple(self.x[0].shape), f32, self.device)
 
     def xbuf(self, j):
         return self.x[j] if self.save else self.x[j % 3]
@@ -318,9 +335,14 @@ class VitRunner:
             ops.cls_rows(xs, W.f("cls_token").view(-1), pos, sg.n_img, sg.N, D)
             ops.linear(sg.patches, W.w("patch_embed.proj.weight").view(D, 768), xs, sg.n_img * sg.P, D, 768,
                        epilogue=E.EPI_BIAS | E.EPI_POS, bias=W.f("patch_embed.proj.bias"), pos=pos, P=sg.P)
+        # --drop: counter-based masks at the four nn.Dropout sites (gv_dropout / gv_dropout_add); the residual adds then run unfused
+        dp = G.dropout
+        dseed = (lambda layer, site: ops.dropout_site_seed(dp[1], layer, site)) if dp else None
+        if dp:
+            ops.dropout(x0, dseed(0, 0), dp[0], n=T * D)                                  # pos_drop
         # D = 384 (ViT-S): proj / fc2 run as full-row products with the residual add AND the LayerNorm that reads the new
         # row next fused into the epilogue (gv_linear_ln_fwd) -- only block 0's norm1 is a stand-alone pass
-        fused = self.fused
+        fused = self.fused and dp is None
         for i in range(self.depth):
             b, s = f"blocks.{i}.", G.slot(i)
             xa, xb, xc = G.xbuf(2 * i), G.xbuf(2 * i + 1), G.xbuf(2 * i + 2)
@@ -340,12 +362,18 @@ class VitRunner:
                 ops.linear_ln_fwd(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, bias=W.f(b + "attn.proj.bias"), resid=xa,
                                   gamma=W.f(b + "norm2.weight"), beta=W.f(b + "norm2.bias"), y=G.xn2[s], mean=st[2], rstd=st[3], row_scale=rs_a)
             else:
-                ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
-                           bias=W.f(b + "attn.proj.bias"), resid=xa, row_scale=rs_a)
+                if dp:
+                    ops.linear(G.o[s], W.w(b + "attn.proj.weight"), G.tmp, T, D, D, epilogue=E.EPI_BIAS, bias=W.f(b + "attn.proj.bias"))
+                    ops.dropout_add(G.tmp, xa, xb, T, D, dseed(i, 1), dp[0], row_scale=rs_a)
+                else:
+                    ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
+                               bias=W.f(b + "attn.proj.bias"), resid=xa, row_scale=rs_a)
                 ops.layernorm_fwd(xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), T, D, y=G.xn2[s], mean=st[2], rstd=st[3])
             ops.linear(G.xn2[s], W.w(b + "mlp.fc1.weight"), G.h[s], T, 4 * D, D,
                        epilogue=E.EPI_BIAS | E.EPI_GELU | (E.EPI_SAVE_PRE if G.save else 0),   # a forward-only group keeps no pre-activation
                        bias=W.f(b + "mlp.fc1.bias"), aux_out=G.hp[s] if G.save else None)
+            if dp:
+                ops.dropout(G.h[s], dseed(i, 2), dp[0], n=T * 4 * D)
             if fused:
                 nxt = i + 1 < self.depth
                 nb, ns = f"blocks.{i + 1}.", G.slot(i + 1)
@@ -353,6 +381,9 @@ class VitRunner:
                                   gamma=W.f(nb + "norm1.weight") if nxt else None, beta=W.f(nb + "norm1.bias") if nxt else None,
                                   y=G.xn1[ns] if nxt else None, mean=G.stats[ns][0] if nxt else None, rstd=G.stats[ns][1] if nxt else None,
                                   row_scale=rs_m)
+            elif dp:
+                ops.linear(G.h[s], W.w(b + "mlp.fc2.weight"), G.tmp, T, D, 4 * D, epilogue=E.EPI_BIAS, bias=W.f(b + "mlp.fc2.bias"))
+                ops.dropout_add(G.tmp, xb, xc, T, D, dseed(i, 3), dp[0], row_scale=rs_m)
             else:
                 ops.linear(G.h[s], W.w(b + "mlp.fc2.weight"), xc, T, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
                            bias=W.f(b + "mlp.fc2.bias"), resid=xb, row_scale=rs_m)
@@ -373,6 +404,15 @@ class VitRunner:
         E = L
         ACC = E.EPI_ACCUM
         grouped = self.group_dw
+        # --drop: the gradient entering a dropout site carries that site's mask (regenerated from the step seed); the bias gradients
+        # of attn.proj / mlp.fc2 are then column sums of the MASKED gradient, not LayerNorm backward's third sum
+        dp = G.dropout
+        dseed = (lambda layer, site: ops.dropout_site_seed(dp[1], layer, site)) if dp else None
+        fused_b = self.fused and dp is None
+
+        def drop_branch_grad(gb, layer, site, bias_grad):
+            ops.dropout(gb, dseed(layer, site), dp[0], n=T * D)
+            ops.colsum(gb, T, D, self.cs_ws, bias_grad, accumulate=True)
         sets = ((G.gb, G.gb2, G.dh, G.dqkv), (G.gb3, G.gb4, G.dh_b, G.dqkv_b))      # per block parity: dY of the MLP / attention half, dh, dqkv
         gb_first = sets[(self.depth - 1) & 1][0] if grouped else G.gb
         G.g.zero_(); gb_first.zero_()
@@ -384,7 +424,7 @@ class VitRunner:
             ops.layernorm_bwd(dfeat[sg.img0:sg.img0 + sg.n_img], sg.rows(xl), sg.fstats[0], sg.fstats[1], W.f("norm.weight"), sg.rows(G.g),
                               sg.rows(gb_first), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True,
                               gb_scale=None if rs is None else G.drop_img[self.depth - 1, 1, sg.img0:sg.img0 + sg.n_img])
-            self._fin3(W.g("norm.weight"), W.g("norm.bias"), W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
+            self._fin3(W.g("norm.weight"), W.g("norm.bias"), None if dp else W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
         # The weight-gradient GEMMs are off the critical path (nothing in backward consumes dW):
         # they run on a side stream beside the dX chain, so their tiles fill the tail of every
         # main-stream kernel (a 345 x 3-tile GEMM occupies 2.02 rounds of the 512 workgroup slots).
@@ -427,7 +467,7 @@ class VitRunner:
             k = ring_i[0]
             ring_i[0] = (k + 1) % 3
             join(fin_ev[k])
-            if dx_of is not None and self.fused:
+            if dx_of is not None and fused_b:
                 nblk = ops.linear_ln_bwd(dx_of[0], dx_of[1], x, mean, rstd, gamma, G.g, gb, ring[k], T, dx_of[2], gb_scale=gb_scale)
             else:
                 if dx_of is not None:
@@ -471,16 +511,22 @@ class VitRunner:
             gb_mlp, gb_att, dh, dqkv = sets[par]
             gb_next = sets[par ^ 1][0]                    # dY of block i - 1's MLP half
             join(done_grp[par])                           # block i + 2's group read this parity's buffers
+            if dp:
+                drop_branch_grad(gb_mlp, i, 3, W.g(b + "mlp.fc2.bias"))
             ops.linear(gb_mlp, W.w(b + "mlp.fc2.weight"), dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
+            if dp:
+                ops.dropout(dh, dseed(i, 2), dp[0], n=T * 4 * D)
             ln_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), gb_att,
-                   W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"),
+                   W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), None if dp else W.g(b + "attn.proj.bias"),
                    dx_of=(dh, W.w(b + "mlp.fc1.weight"), 4 * D), gb_scale=None if rs is None else rs[i, 0])
+            if dp:
+                drop_branch_grad(gb_att, i, 1, W.g(b + "attn.proj.bias"))
             ops.linear(gb_att, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             for sg in G.segs:
                 ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(dqkv))
             join(done_grp[par ^ 1])                       # block i + 1's group read gb_next (its MLP-half dY)
             ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
-                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
+                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if (i > 0 and not dp) else None,
                    dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])
             probs = [(gb_mlp, G.h[i], W.g(b + "mlp.fc2.weight"), None),
                      (dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), W.g(b + "mlp.fc1.bias")),
@@ -496,13 +542,19 @@ class VitRunner:
             b, st = f"blocks.{i}.", G.stats[i]
             # MLP
             join(done_fc1)               # last block's dW_fc1 read dh
+            if dp:
+                drop_branch_grad(gbs[0], i, 3, W.g(b + "mlp.fc2.bias"))
             ops.linear(gbs[0], W.w(b + "mlp.fc2.weight"), G.dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
+            if dp:
+                ops.dropout(G.dh, dseed(i, 2), dp[0], n=T * 4 * D)
             done_fc2 = dw(gbs[0], G.h[i], W.g(b + "mlp.fc2.weight"), D, 4 * D)
             done_fc1 = dw(G.dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), 4 * D, D, colsum_a=W.g(b + "mlp.fc1.bias"))
             join(done_proj)              # last block's dW_proj read gb2
             ln_bwd(G.dxn, G.x[2 * i + 1], st[2], st[3], W.f(b + "norm2.weight"), gbs[1],
-                   W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"),
+                   W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), None if dp else W.g(b + "attn.proj.bias"),
                    dx_of=(G.dh, W.w(b + "mlp.fc1.weight"), 4 * D), gb_scale=None if rs is None else rs[i, 0])
+            if dp:
+                drop_branch_grad(gbs[1], i, 1, W.g(b + "attn.proj.bias"))
             # attention
             ops.linear(gbs[1], W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             done_proj = dw(gbs[1], G.o[i], W.g(b + "attn.proj.weight"), D, D)
@@ -512,11 +564,13 @@ class VitRunner:
             done_qkv = dw(G.dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), 3 * D, D, colsum_a=W.g(b + "attn.qkv.bias"))
             join(done_fc2)               # this block's dW_fc2 read gb
             ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gbs[0],
-                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
+                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if (i > 0 and not dp) else None,
                    dx_of=(G.dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])
             report(i)
         join(done_qkv)          # every dW product is in (the side stream runs them in order); ws is free again
         join(last_side[0])      # ... and the last finalize
+        if dp:
+            ops.dropout(G.g, dseed(0, 0), dp[0], n=T * D)                                 # pos_drop's mask on the token gradient
         # token assembly + patch embedding, per segment
         gpos = W.g("pos_embed").view(-1, D)
         for sg in G.segs:
@@ -734,6 +788,10 @@ class DinoEngine:
         """Stochastic depth for the STUDENT's next steps (the teacher runs without, as in DINO): f32 [depth, 2, V * B] on the
         device, keep / (1 - p) per crop image (global crops first, crop-major like the feature rows), or None."""
         self.g_stu.set_drop(per_img)
+
+    def set_dropout(self, p: float, seed: int = 0):
+        """--drop for the STUDENT's next step (the teacher runs in eval mode): probability and this step's 32-bit seed; p = 0 switches it off."""
+        self.g_stu.set_dropout(p, seed)
 
     def set_hyper(self, lr=None, wd=None, momentum_teacher=None, teacher_temp=None, n_micro: int = 1):
         """Put the per-step schedule values into the device hyper vector with a tiny stream-ordered
@@ -993,6 +1051,10 @@ class SupervisedEngine:
         """Stochastic depth (--drop-path) for the next training steps: f32 [depth, 2, batch] on the device = keep / (1 - p)
         per image and residual branch, or None (evaluation: ``forward`` with it set would scale the branches too)."""
         self.grp.set_drop(per_img)
+
+    def set_dropout(self, p: float, seed: int = 0):
+        """--drop for the next training steps' forward / backward: probability and the step's 32-bit seed (evaluation: p = 0)."""
+        self.grp.set_dropout(p, seed)
 
     def grads(self):
         return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}

@@ -226,8 +226,8 @@ def create_model(model_name: str, pretrained: bool = False, in_chans: int = 3, n
     arch = resolve_arch(model_name)
     if in_chans != 3:
         raise ValueError(f"create_model: in_chans={in_chans}; the hot path is built for RGB tiles")
-    if drop_rate:
-        raise ValueError("create_model: dropout (drop_rate) is not built (DESIGN.md section 6); stochastic depth (drop_path_rate) is")
+    if drop_rate and not 0.0 <= drop_rate < 1.0:
+        raise ValueError(f"create_model: drop_rate {drop_rate}: need 0 <= rate < 1")
     if pretrained and not checkpoint_path:
         raise ValueError("create_model: pretrained=True needs checkpoint_path (no network on this system)")
     C = 2 if num_classes is None else int(num_classes)
@@ -236,6 +236,8 @@ def create_model(model_name: str, pretrained: bool = False, in_chans: int = 3, n
     eng.load_state(state)
     model = VitModel(eng, arch)
     # stochastic depth: the training loop hands the next step's draws to the engine -- engine.set_drop_path(model.drop_path.sample())
+    # dropout: like the stochastic-depth draws, the training loop hands each step its seed -- engine.set_dropout(model.drop_rate, seed)
+    model.drop_rate = float(drop_rate or 0.0)
     model.drop_path_rate = float(drop_path_rate or 0.0)
     model.drop_path = None
     if model.drop_path_rate:

@@ -397,3 +397,30 @@ def agc(p, grad, units, clip_factor: float, eps: float = 1e-3, grad_scale: float
     """Adaptive gradient clipping in place on ``grad`` (units: device int32 [n, 2] from agc_units); see gv_agc."""
     assert units.dtype == torch.int32 and units.is_contiguous() and units.device == grad.device
     L.call("gv_agc", L.gv_agc_args(p.data_ptr(), grad.data_ptr(), units.data_ptr(), units.shape[0], clip_factor, eps, grad_scale), _stream())
+
+
+def dropout_threshold(p: float) -> int:
+    """keep iff hash >= floor(p * 2^32) (gv_dropout)."""
+    return min(int(p * 4294967296.0), 4294967295)
+
+
+def dropout_site_seed(seed: int, layer: int, site: int) -> int:
+    """The seed of one dropout site of one step: murmur3 finaliser of (step seed, layer, site); sites: 0 pos-embed, 1 attn.proj,
+    2 MLP activation, 3 mlp.fc2.  (Restated in oracle/vit_oracle.py for the checker.)"""
+    h = (seed ^ (0x85EBCA6B * (layer * 8 + site + 1))) & 0xFFFFFFFF
+    h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF; h ^= h >> 16
+    return h
+
+
+def dropout(x, seed: int, p: float, n: Optional[int] = None):
+    """In place on a contiguous bf16 / f32 tensor: nn.Dropout(p) with the counter-based mask of (seed, element index); see gv_dropout."""
+    assert x.is_contiguous() and x.dtype in (bf16, f32)
+    a = L.gv_dropout_args(x.data_ptr(), int(x.dtype == f32), x.numel() if n is None else n, seed, dropout_threshold(p), 1.0 / (1.0 - p))
+    L.call("gv_dropout", a, _stream())
+
+
+def dropout_add(t, resid, out, rows: int, cols: int, seed: int, p: float, row_scale=None):
+    """out = resid + row_scale * dropout(t) (all f32 [rows, cols]); see gv_dropout_add."""
+    assert t.dtype == f32 and resid.dtype == f32 and out.dtype == f32
+    a = L.gv_dropout_add_args(t.data_ptr(), resid.data_ptr(), out.data_ptr(), _p(row_scale), rows, cols, seed, dropout_threshold(p), 1.0 / (1.0 - p))
+    L.call("gv_dropout_add", a, _stream())

@@ -488,6 +488,23 @@ typedef struct {
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
 
+/* ---- dropout (`--drop`, reference train.py:283-284 -> create_model(drop_rate): nn.Dropout after the pos-embed add, after attn.proj,
+ * after the MLP activation and after mlp.fc2; vit.pyc@L98-104, L119-131, L235-246).  Counter-based masks, so that the backward
+ * regenerates what the forward used and the oracle can restate it: element i of a site is KEPT iff
+ *   fmix32(seed + 0x9E3779B9 * (i + 1)) >= threshold,   threshold = floor(p * 2^32)   (murmur3 finaliser)
+ * and kept values are scaled by `scale` = 1 / (1 - p).  `seed` is the site's own (host: one per step, layer and site).
+ * gv_dropout: in place on x (bf16, or f32 with x_is_f32) -- an activation in the forward, the gradient entering the same site
+ * in the backward.  gv_dropout_add: out[m, :] = resid[m, :] + row_scale[m] * dropout(t[m, :]) for the two residual branches
+ * (t = the branch's Linear output incl. bias, f32; row_scale: stochastic depth, may be NULL).  Element index = m * cols + c.
+ * These run only when --drop > 0 (the step then takes the unfused Linear / LayerNorm kernels); the default path is untouched. */
+typedef struct { void* x; int32_t x_is_f32; int64_t n; uint32_t seed, threshold; float scale; } gv_dropout_args;
+int gv_dropout(const gv_dropout_args* a, void* stream);
+typedef struct {
+    const float* t; const float* resid; float* out; const float* row_scale;
+    int32_t rows, cols; uint32_t seed, threshold; float scale;
+} gv_dropout_add_args;
+int gv_dropout_add(const gv_dropout_add_args* a, void* stream);
+
 /* ---- adaptive gradient clipping (`--clip-mode agc`, reference train.py:1072-1077 -> timm.utils.adaptive_clip_grad): per UNIT
  * (a row of a matrix / conv filter = dim 0 of the parameter; a whole tensor for 1-D parameters and for tensors whose dim 0 is 1)
  *   g_u <- g_u * min(1, clip_factor * max(||p_u||, eps) / max(||g_u||, 1e-6)),   g_u = grad_u * grad_scale for the norms

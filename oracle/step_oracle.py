@@ -52,7 +52,7 @@ class DinoOracle:
     def crops(self, tiles_u8):
         return [vo.normalize_window(tiles_u8, w, dtype=self.dtype) for w in self.wins]
 
-    def forward_backward(self, tiles_u8, teacher_temp=None, drop=None):
+    def forward_backward(self, tiles_u8, teacher_temp=None, drop=None, dropout=None):
         """``drop``: stochastic-depth factors of the STUDENT pass, [depth, 2, V * B] in crop order (vo.drop_path_factors); the
         teacher runs without (DINO: teacher in eval mode)."""
         crops = self.crops(tiles_u8)
@@ -60,7 +60,7 @@ class DinoOracle:
         with torch.no_grad():
             t_out = vo.multicrop_forward(self.tp, self.thp, crops[:G], self.arch)
         sp, shp = _leafify(self.p), _leafify(self.hp)
-        s_out = vo.multicrop_forward(sp, shp, crops, self.arch, drop=drop)
+        s_out = vo.multicrop_forward(sp, shp, crops, self.arch, drop=drop, dropout=dropout)     # dropout = (p, step seed): student only
         loss, bsum = vo.dino_loss(s_out, t_out, self.center, V, G, self.ts, self.tt if teacher_temp is None else teacher_temp)
         loss.backward()
         grads = {**{"backbone." + k: v.grad for k, v in sp.items()},
@@ -96,10 +96,10 @@ class SupervisedOracle:
         self.smoothing = smoothing
         self.opt = vo.Lamb(self.p, lr, wd) if opt == "lamb" else vo.AdamW(self.p, lr, wd)
 
-    def forward_backward(self, tiles_u8, target, drop=None):
+    def forward_backward(self, tiles_u8, target, drop=None, dropout=None):
         x = vo.normalize_window(tiles_u8, (0, 0, self.img), dtype=self.dtype)
         sp = _leafify(self.p)
-        logits = vo.vit_logits(sp, x, self.arch, drop=drop)
+        logits = vo.vit_logits(sp, x, self.arch, drop=drop, dropout=None if dropout is None else (dropout[0], dropout[1], 0))
         loss = vo.softmax_lsce(logits, target, self.smoothing)
         loss.backward()
         return loss.detach(), {k: v.grad for k, v in sp.items()}, logits.detach()

@@ -139,6 +139,36 @@ def gelu(x):
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
+def dropout_site_seed(seed: int, layer: int, site: int) -> int:
+    """Restatement of the product's per-site seed (gipvit.ops.dropout_site_seed): murmur3 finaliser of (step seed, layer, site)."""
+    h = (seed ^ (0x85EBCA6B * (layer * 8 + site + 1))) & 0xFFFFFFFF
+    h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF; h ^= h >> 16
+    return h
+
+
+def dropout_mask(seed: int, first: int, n: int, p: float) -> torch.Tensor:
+    """keep / (1 - p) factors of elements [first, first + n) of a dropout site (include/gipvit.h gv_dropout): element i is kept iff
+    fmix32(seed + 0x9E3779B9 (i + 1)) >= floor(p 2^32).  nn.Dropout semantics with the product's counter-based stream."""
+    import numpy as np
+    i = (np.arange(first, first + n, dtype=np.uint64) + 1) & np.uint64(0xFFFFFFFF)
+    h = (np.uint64(seed) + np.uint64(0x9E3779B9) * i) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    thr = min(int(p * 4294967296.0), 4294967295)
+    return torch.from_numpy((h >= np.uint64(thr)).astype(np.float32) * np.float32(1.0 / (1.0 - p)))      # the product's scale: float32(1 / (1 - p))
+
+
+def _drop(x, dropout, layer, site):
+    """Apply the dropout of (layer, site) to x [B, N, C]; dropout = (p, step seed, first row of this group in the site's row space)."""
+    if dropout is None:
+        return x
+    p, seed, row0 = dropout
+    B, N, C = x.shape
+    m = dropout_mask(dropout_site_seed(seed, layer, site), row0 * C, B * N * C, p).reshape(B, N, C)
+    return x * m.to(x.dtype)
+
+
 def attention(x, p, pre, num_heads):
     """vit.pyc@L119-131 Attention.forward."""
     B, N, C = x.shape
@@ -165,15 +195,19 @@ def drop_path_factors(depth: int, n_img: int, rate: float, gen: torch.Generator)
     return out
 
 
-def block(x, p, i, num_heads, drop=None):
+def block(x, p, i, num_heads, drop=None, dropout=None):
     """vit.pyc@L146-152 Block.forward.  ``drop``: f32 [2, B] stochastic-depth factors of this block's two branches
-    (drop_path_factors), None = Identity (rate 0 / evaluation)."""
+    (drop_path_factors), None = Identity (rate 0 / evaluation).  ``dropout``: (p, step seed, row0) -- nn.Dropout after attn.proj
+    (site 1), after the MLP activation (site 2) and after mlp.fc2 (site 3), with the product's counter-based masks."""
     b = f"blocks.{i}."
     a = attention(layer_norm(x, p[b + "norm1.weight"], p[b + "norm1.bias"]), p, b + "attn.", num_heads)
+    a = _drop(a, dropout, i, 1)
     x = x + (a if drop is None else a * drop[0].to(a.dtype)[:, None, None])
     h = layer_norm(x, p[b + "norm2.weight"], p[b + "norm2.bias"])
     h = gelu(h @ p[b + "mlp.fc1.weight"].t() + p[b + "mlp.fc1.bias"])
+    h = _drop(h, dropout, i, 2)
     h = h @ p[b + "mlp.fc2.weight"].t() + p[b + "mlp.fc2.bias"]
+    h = _drop(h, dropout, i, 3)
     return x + (h if drop is None else h * drop[1].to(h.dtype)[:, None, None])
 
 
@@ -186,20 +220,20 @@ def prepare_tokens(x, p):
     return t + interpolate_pos_encoding(p["pos_embed"], t.shape[1] - 1, w, h)
 
 
-def vit_features(p, x, arch: str, return_tokens: bool = False, drop=None):
+def vit_features(p, x, arch: str, return_tokens: bool = False, drop=None, dropout=None):
     """vit.pyc@L248-253 VisionTransformer.forward -> x[:, 0] after the final norm.  ``drop``: [depth, 2, B] stochastic-depth
-    factors (training with --drop-path) or None."""
+    factors (training with --drop-path) or None.  ``dropout``: (p, step seed, row0) for --drop (pos_drop is site 0 of layer 0)."""
     a = ARCHS[arch]
-    t = prepare_tokens(x, p)
+    t = _drop(prepare_tokens(x, p), dropout, 0, 0)
     for i in range(a["depth"]):
-        t = block(t, p, i, a["num_heads"], None if drop is None else drop[i])
+        t = block(t, p, i, a["num_heads"], None if drop is None else drop[i], dropout)
     t = layer_norm(t, p["norm.weight"], p["norm.bias"])
     return t if return_tokens else t[:, 0]
 
 
-def vit_logits(p, x, arch: str, drop=None):
+def vit_logits(p, x, arch: str, drop=None, dropout=None):
     """timm variant used at runtime (train.py:482-495): CLS -> head Linear."""
-    f = vit_features(p, x, arch, drop=drop)
+    f = vit_features(p, x, arch, drop=drop, dropout=dropout)
     return f @ p["head.weight"].t() + p["head.bias"]
 
 
@@ -290,18 +324,21 @@ def ema_update(teacher: Dict[str, torch.Tensor], student: Dict[str, torch.Tensor
 # --------------------------------------------------------------------------- #
 # multi-crop forward (row D1)
 # --------------------------------------------------------------------------- #
-def multicrop_forward(p, hp, crops: Sequence[torch.Tensor], arch: str, drop=None):
+def multicrop_forward(p, hp, crops: Sequence[torch.Tensor], arch: str, drop=None, dropout=None):
     """Group consecutive crops of equal resolution, run the backbone once per
     group on the concatenated batch, concat CLS features, head once.  ``drop``: [depth, 2, sum of crop batches]
     stochastic-depth factors in crop order (every crop of every image is its own sample), or None."""
-    feats, i, img0 = [], 0, 0
+    feats, i, img0, row0 = [], 0, 0, 0          # row0: first token row of the group in the token-concatenated row space (dropout indices)
     while i < len(crops):
         j = i
         while j < len(crops) and crops[j].shape[-1] == crops[i].shape[-1]:
             j += 1
         x = torch.cat(list(crops[i:j]))
-        feats.append(vit_features(p, x, arch, drop=None if drop is None else drop[:, :, img0:img0 + x.shape[0]]))
+        ntok = (x.shape[-1] // PATCH) ** 2 + 1
+        feats.append(vit_features(p, x, arch, drop=None if drop is None else drop[:, :, img0:img0 + x.shape[0]],
+                                  dropout=None if dropout is None else (dropout[0], dropout[1], row0)))
         img0 += x.shape[0]
+        row0 += x.shape[0] * ntok
         i = j
     return dino_head(hp, torch.cat(feats))
 

@@ -354,7 +354,8 @@ def test_create_model_seam(dev):
     with pytest.raises(KeyError):
         m.load_state_dict({"head.bias": sd["head.bias"]})
     with pytest.raises(ValueError, match="drop"):
-        models.create_model("vit_tiny", drop_rate=0.1, device=dev)
+        models.create_model("vit_tiny", drop_rate=1.0, device=dev)
+    assert models.create_model("vit_tiny", num_classes=2, img_size=64, batch=8, drop_rate=0.1, device=dev).drop_rate == 0.1
     md = models.create_model("vit_tiny", num_classes=2, img_size=64, batch=8, drop_path_rate=0.2, device=dev)
     assert md.drop_path_rate == 0.2 and tuple(md.drop_path.sample().shape) == (12, 2, 8)
     with pytest.raises(ValueError, match="checkpoint_path"):
@@ -410,4 +411,57 @@ def test_drop_path_dino_parity(dev):
     torch.cuda.synchronize()
     assert abs(float(eng.loss) - float(loss_r)) <= 1e-3, (float(eng.loss), float(loss_r))
     assert float((eng.hb_s.logits.cpu() - s_out).abs().max()) <= 3e-2 * float(s_out.abs().max())
+    _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))
+
+
+@gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_dropout_supervised_parity(dev, precision):
+    """--drop (nn.Dropout after the pos-embed add, attn.proj, the MLP activation and mlp.fc2): engine and oracle draw the SAME
+    counter-based masks from (p, step seed); logits, loss and every gradient agree -- to 1e-4 / 1e-3 in the fp32 operand mode, at
+    the bf16 gates on the training path -- together with stochastic depth; the masks change the result and p = 0 restores it."""
+    from gipvit.engine import SupervisedEngine
+    from oracle import step_oracle as so, vit_oracle as vo
+    orc = so.SupervisedOracle(arch="vit_tiny", img_size=64, num_classes=2, seed=0, lr=1e-3, wd=0.05)
+    eng = SupervisedEngine(arch="vit_tiny", img_size=64, num_classes=2, batch=8, lr=1e-3, weight_decay=0.05, device=dev, precision=precision)
+    eng.load_state(orc.p)
+    tiles = vo.synth_tiles(8, 64, seed=1234)
+    tgt = torch.randint(0, 2, (8, 1), generator=torch.Generator().manual_seed(5))
+    drop = vo.drop_path_factors(12, 8, 0.2, torch.Generator().manual_seed(9))
+    loss_0, _, _ = orc.forward_backward(tiles, tgt, drop)
+    loss_r, grads_r, logits_r = orc.forward_backward(tiles, tgt, drop, dropout=(0.15, 4242))
+    assert abs(float(loss_r) - float(loss_0)) > 1e-3
+    eng.set_drop_path(drop.to(dev)); eng.set_dropout(0.15, 4242)
+    eng.forward_backward(tiles.to(dev), tgt.to(dev))
+    torch.cuda.synchronize()
+    tol_l, tol_g = (1e-4, 1e-3) if precision == "fp32" else (1e-3, 5e-2)
+    assert float((eng.logits.cpu() - logits_r).abs().max()) <= (1e-4 if precision == "fp32" else 2e-2) * max(float(logits_r.abs().max()), 1.0)
+    assert abs(float(eng.loss) - float(loss_r)) <= tol_l, (float(eng.loss), float(loss_r))
+    _check_grads(eng.grads(), grads_r, tol=tol_g)
+    eng.set_dropout(0.0)
+    eng.forward_backward(tiles.to(dev), tgt.to(dev))
+    assert abs(float(eng.loss) - float(loss_0)) <= tol_l
+
+
+@gpu
+def test_dropout_dino_parity(dev):
+    """--drop in the DINO step at the headline width (ViT-S: the run leaves the fused Linear + LayerNorm kernels for the unfused pair,
+    wide products and grouped weight gradients stay): the student gets the masks, the teacher none."""
+    from gipvit.engine import DinoEngine
+    from oracle import step_oracle as so, vit_oracle as vo
+    K, B = 2048, 4
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    orc = so.DinoOracle(arch="vit_small", img_size=224, out_dim=K, seed=0, lr=5e-4, wd=0.04)
+    eng = DinoEngine(arch="vit_small", img_size=224, out_dim=K, batch=B, lr=5e-4, weight_decay=0.04, device=dev)
+    eng.load_state(orc.p, orc.hp)
+    tiles = vo.synth_tiles(B, 256, seed=78)
+    loss_0 = orc.forward_backward(tiles)[0]
+    loss_r, grads_r, s_out, t_out, bsum = orc.forward_backward(tiles, dropout=(0.1, 99))
+    assert abs(float(loss_r) - float(loss_0)) > 1e-4
+    eng.set_hyper(); eng.set_dropout(0.1, 99)
+    eng.forward_backward(tiles.to(dev))
+    torch.cuda.synchronize()
+    assert abs(float(eng.loss) - float(loss_r)) <= 1.5e-3, (float(eng.loss), float(loss_r))       # B = 4 (the B = 8 configs hold 1e-3)
+    assert float((eng.hb_s.logits.cpu() - s_out).abs().max()) <= 3e-2 * float(s_out.abs().max())
+    assert float((eng.hb_t.logits.cpu() - t_out).abs().max()) <= 2e-2 * float(t_out.abs().max())
     _check_grads(eng.grads(), grads_r, skip=("head.last_layer.weight_g",))

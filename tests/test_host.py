@@ -305,7 +305,7 @@ def test_every_used_flag_is_read_by_the_driver():
         elif e["flags"][0] != "data":
             assert reads == 0, f"{e['flags']} is read by train.py but marked used=False"
     # values the build cannot honour are refused before any GPU work
-    for bad in (["--drop", "0.1"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "adaptive"], ["--clip-mode", "agc", "--dino"], ["--clip-mode", "value", "--opt", "lamb"], ["--in-chans", "1"],
+    for bad in (["--drop", "1.0"], ["--drop-path", "1.0"], ["--drop-connect", "0.1"], ["--pretrained"], ["--clip-mode", "adaptive"], ["--clip-mode", "agc", "--dino"], ["--clip-mode", "value", "--opt", "lamb"], ["--in-chans", "1"],
                 ["--input-size", "3", "224", "200"], ["--dino", "--supervised"], ["--amp", "--amp-dtype", "bfloat16", "--precision", "fp32"],
                 ["--opt", "lars"], ["--opt", "rmsprop"], ["--opt", "nadam"], ["--opt", "momentum"], ["--sched", "tanh"], ["--sched", "plateau"],
                 ["--sched", "multistep"], ["--sched", "poly"], ["--dino", "--opt", "sgd"], ["--dino", "--opt", "adam"], ["--dino", "--opt", "lamb"]):
@@ -419,6 +419,6 @@ def test_create_model_rejects_what_is_not_built():
     with pytest.raises(ValueError, match="in_chans"):
         models.create_model("vit_tiny", in_chans=1)
     with pytest.raises(ValueError, match="drop"):
-        models.create_model("vit_small_patch16_224", drop_rate=0.1)
+        models.create_model("vit_small_patch16_224", drop_rate=1.0)
     with pytest.raises(ValueError, match="checkpoint_path"):
         models.create_model("vit_small_patch16_224", pretrained=True)

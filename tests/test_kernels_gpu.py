@@ -597,6 +597,29 @@ def test_attention_fwd_varlen(dev, segs):
     close(out[:n * N], ref, 2e-2, 2e-2, "varlen vs sdpa")
 
 
+@pytest.mark.parametrize("dt", [bf16, f32])
+def test_dropout_kernels(dev, dt):
+    """gv_dropout / gv_dropout_add: the counter-based keep mask of (seed, element index) equals the oracle's numpy restatement bit for
+    bit, kept values are scaled by 1 / (1 - p); the per-site seed function matches; p near 0 and near 1."""
+    from oracle import vit_oracle as vo
+    o = ops()
+    n = 257 * 384 + 3
+    assert o.dropout_site_seed(123456, 7, 2) == vo.dropout_site_seed(123456, 7, 2) and o.dropout_site_seed(1, 0, 0) != o.dropout_site_seed(1, 0, 1)
+    for p, seed in ((0.1, 5), (0.5, 0xDEADBEEF), (0.999, 77), (1e-6, 3)):
+        x = torch.randn(n, generator=torch.Generator().manual_seed(1)).to(dev).to(dt)
+        ref = (x.float().cpu() * vo.dropout_mask(seed, 0, n, p)).to(dt)
+        o.dropout(x, seed, p)
+        assert torch.equal(x.cpu(), ref), (p, seed)
+    rows, cols = 301, 192
+    t = torch.randn(rows, cols, generator=torch.Generator().manual_seed(2)).to(dev)
+    resid = torch.randn(rows, cols, generator=torch.Generator().manual_seed(3)).to(dev)
+    rs = (torch.rand(rows, generator=torch.Generator().manual_seed(4)) * 2).to(dev)
+    out = torch.empty_like(t)
+    o.dropout_add(t, resid, out, rows, cols, 31337, 0.2, row_scale=rs)
+    m = vo.dropout_mask(31337, 0, rows * cols, 0.2).view(rows, cols)
+    close(out.cpu(), resid.cpu() + rs.cpu()[:, None] * (t.cpu() * m), 1e-6, 1e-6, "dropout_add")
+
+
 def test_agc_matches_oracle(dev):
     """gv_agc (--clip-mode agc, timm adaptive_clip_grad) against the oracle's restatement: rows of matrices and conv filters, whole 1-D
     tensors and dim-0-of-one tensors are units; only units whose gradient norm exceeds clip_factor * max(||p||, eps) are rescaled."""

@@ -177,7 +177,7 @@ def test_train_opt_values_select_their_own_arithmetic(dev, tmp_path):
             "--output", str(tmp_path), "--seed", "3", "--no-validate", "--clip-grad", "0.5"]
     ends = {}
     for name, extra in (("sgd", ["--opt", "sgd"]), ("adam", ["--opt", "adam"]), ("adamw", ["--opt", "adamw"]), ("lamb", ["--opt", "lamb"]),
-                        ("adamw_val", ["--opt", "adamw", "--clip-mode", "value"]), ("adamw_agc", ["--opt", "adamw", "--clip-mode", "agc", "--clip-grad", "0.01"])):
+                        ("adamw_val", ["--opt", "adamw", "--clip-mode", "value"]), ("adamw_drop", ["--opt", "adamw", "--drop", "0.1"]), ("adamw_agc", ["--opt", "adamw", "--clip-mode", "agc", "--clip-grad", "0.01"])):
         assert train.main(base + ["--experiment", name] + extra) == 0
         ck = torch.load(tmp_path / name / "last.pth.tar", weights_only=True)
         ends[name] = ck["state_dict"]["blocks.5.mlp.fc1.weight"]

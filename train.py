@@ -128,9 +128,8 @@ SUPPORTED_SCHEDS = ("cosine", "step")               # gipvit/sched.py
 def check_supported(args, log=_logger.warning):
     """Reference flags whose value this build cannot honour are rejected loudly; the ones it maps onto its own
     arithmetic are explained once.  Returns the resolved image size (or None)."""
-    if args.drop:
-        raise SystemExit(f"--drop {args.drop}: dropout is not built into the fused epilogues (reference train.py:283-284, vit.pyc@L98-104); "
-                         "only the reference default 0.0 is supported")
+    if args.drop and not 0.0 <= args.drop < 1.0:
+        raise SystemExit(f"--drop {args.drop}: dropout needs 0 <= rate < 1 (reference train.py:283-284, vit.pyc@L98-131)")
     if args.drop_path is not None and not 0.0 <= args.drop_path < 1.0:
         raise SystemExit(f"--drop-path {args.drop_path}: stochastic depth needs 0 <= rate < 1 (reference train.py:287-288, vit.pyc@L66-74)")
     if args.drop_connect:
@@ -395,6 +394,11 @@ def main(argv=None):
         drop_sampler = DropPathSampler(ARCHS[arch]["depth"], (eng.V * B) if args.dino else B, args.drop_path, args.seed + 17 * rank, dev)
         if args.resume and isinstance(ck.get("drop_path_rng"), dict):
             drop_sampler.load_state_dict(ck["drop_path_rng"])
+    # --drop (train.py:283-284): nn.Dropout at the four sites of the encoder, a fresh 32-bit seed per step (counter-based masks)
+    drop_rng = None
+    if args.drop:
+        import numpy as np
+        drop_rng = np.random.default_rng(args.seed + 7919 * rank + 11)
     cur_lr = lr
     # ---- epoch loop (train.py:905-977) / step loop (988-1143)
     for epoch in range(start_epoch, args.epochs):
@@ -413,6 +417,8 @@ def main(argv=None):
             cur_lr = schedule.at(epoch, batch_idx)
             if drop_sampler is not None:
                 eng.set_drop_path(drop_sampler.sample())
+            if drop_rng is not None:
+                eng.set_dropout(args.drop, int(drop_rng.integers(0, 1 << 32)))
             if args.dino:
                 it = epoch * updates_per_epoch + batch_idx
                 sch = dict(lr=cur_lr, wd=S.cosine_between(args.weight_decay, args.weight_decay_end, it, total_updates),
