@@ -10,8 +10,14 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# The 16-bit operand / activation format is a property of the library BUILD (include/gipvit.h gv_act_format): bfloat16 in
+# libgipvit_hip.so, IEEE half in libgipvit_hip_f16.so (the same sources with -DGV_ACT_F16; --amp --amp-dtype float16).  One
+# process computes in one format: GIPVIT_ACT_FORMAT picks it before the first import of this module.
+ACT_FORMAT = os.environ.get("GIPVIT_ACT_FORMAT", "bf16")
+if ACT_FORMAT not in ("bf16", "f16"):
+    raise ImportError(f"GIPVIT_ACT_FORMAT={ACT_FORMAT!r}: 'bf16' or 'f16'")
 # GIPVIT_LIB: a lab build to time against the product library (tools/lab.sh) -- lab runs never overwrite the product file
-LIB_PATH = os.environ.get("GIPVIT_LIB") or os.path.join(HERE, "libgipvit_hip.so")
+LIB_PATH = os.environ.get("GIPVIT_LIB") or os.path.join(HERE, "libgipvit_hip.so" if ACT_FORMAT == "bf16" else "libgipvit_hip_f16.so")
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -87,11 +93,13 @@ gv_weightnorm_bwd_args = _struct("gv_weightnorm_bwd_args", [
     ("dw", vp), ("v", vp), ("g", vp), ("dv", vp), ("dg", vp), ("rows", i32), ("C", i32), ("accumulate", i32)])
 gv_dino_loss_args = _struct("gv_dino_loss_args", [
     ("student", vp), ("teacher", vp), ("center", vp), ("dstudent", vp), ("loss", vp), ("center_sum", vp), ("workspace", vp),
-    ("B", i32), ("V", i32), ("G", i32), ("K", i32), ("student_temp", f32), ("teacher_temp", f32), ("grad_scale", f32), ("hyper", vp)])
+    ("B", i32), ("V", i32), ("G", i32), ("K", i32), ("student_temp", f32), ("teacher_temp", f32), ("grad_scale", f32), ("hyper", vp),
+    ("loss_scale", vp)])
 gv_center_update_args = _struct("gv_center_update_args", [
     ("center", vp), ("center_sum", vp), ("K", i32), ("momentum", f32), ("inv_rows", f32)])
 gv_softmax_lsce_args = _struct("gv_softmax_lsce_args", [
-    ("logits", vp), ("target", vp), ("loss", vp), ("dlogits", vp), ("prob", vp), ("B", i32), ("C", i32), ("smoothing", f32)])
+    ("logits", vp), ("target", vp), ("loss", vp), ("dlogits", vp), ("prob", vp), ("B", i32), ("C", i32), ("smoothing", f32),
+    ("loss_scale", vp)])
 gv_gather_cls_args = _struct("gv_gather_cls_args", [("x", vp), ("y", vp), ("n_img", i32), ("N", i32), ("D", i32)])
 gv_store_f32_args = _struct("gv_store_f32_args", [("dst", vp), ("vals", f32 * 16), ("n", i32)])
 gv_cast_bf16_args = _struct("gv_cast_bf16_args", [("src", vp), ("dst", vp), ("n", i64)])
@@ -99,7 +107,10 @@ gv_sumsq_args = _struct("gv_sumsq_args", [("x", vp), ("n", i64), ("workspace", v
 gv_adamw_ema_args = _struct("gv_adamw_ema_args", [
     ("p", vp), ("grad", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("teacher", vp), ("teacher_bf16", vp), ("n", i64),
     ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bias_corr1", f32), ("bias_corr2", f32),
-    ("grad_scale", f32), ("clip_norm", f32), ("gnorm_sq", vp), ("teacher_momentum", f32), ("hyper", vp), ("mode", i32), ("clip_value", f32)])
+    ("grad_scale", f32), ("clip_norm", f32), ("gnorm_sq", vp), ("teacher_momentum", f32), ("hyper", vp), ("mode", i32), ("clip_value", f32),
+    ("loss_scale", vp)])
+gv_loss_scale_update_args = _struct("gv_loss_scale_update_args", [
+    ("state", vp), ("gnorm_sq", vp), ("growth_factor", f32), ("backoff_factor", f32), ("growth_interval", i32)])
 u32 = C.c_uint32
 gv_dropout_args = _struct("gv_dropout_args", [("x", vp), ("x_is_f32", i32), ("n", i64), ("seed", u32), ("threshold", u32), ("scale", f32)])
 gv_dropout_add_args = _struct("gv_dropout_add_args", [("t", vp), ("resid", vp), ("out", vp), ("row_scale", vp), ("rows", i32), ("cols", i32),
@@ -120,14 +131,14 @@ ENTRY_POINTS = {
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,
     "gv_dino_loss": gv_dino_loss_args, "gv_center_update": gv_center_update_args, "gv_softmax_lsce": gv_softmax_lsce_args,
     "gv_gather_cls": gv_gather_cls_args, "gv_cast_bf16": gv_cast_bf16_args, "gv_store_f32": gv_store_f32_args, "gv_sumsq": gv_sumsq_args,
-    "gv_adamw_ema": gv_adamw_ema_args, "gv_lamb": gv_lamb_args, "gv_agc": gv_agc_args, "gv_dropout": gv_dropout_args, "gv_dropout_add": gv_dropout_add_args,
+    "gv_adamw_ema": gv_adamw_ema_args, "gv_loss_scale_update": gv_loss_scale_update_args, "gv_lamb": gv_lamb_args, "gv_agc": gv_agc_args, "gv_dropout": gv_dropout_args, "gv_dropout_add": gv_dropout_add_args,
     # fp32 operand mode: the same structs with every bf16 buffer read / written as f32
     "gv_linear_f32": gv_linear_args, "gv_attention_fwd_f32": gv_attention_fwd_args, "gv_attention_bwd_f32": gv_attention_bwd_args,
     "gv_layernorm_fwd_f32": gv_layernorm_fwd_args, "gv_layernorm_bwd_f32": gv_layernorm_bwd_args, "gv_patchify_f32": gv_patchify_args,
     "gv_tokens_bwd_f32": gv_tokens_bwd_args, "gv_l2norm_fwd_f32": gv_l2norm_fwd_args, "gv_l2norm_bwd_f32": gv_l2norm_bwd_args,
     "gv_weightnorm_fwd_f32": gv_weightnorm_fwd_args, "gv_dino_loss_f32": gv_dino_loss_args,
 }
-PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_linear_workspace_bytes", "gv_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read",
+PLAIN_SYMBOLS = ("gv_version", "gv_last_error", "gv_target", "gv_act_format", "gv_linear_workspace_bytes", "gv_workspace_bytes", "gv_linear_timing", "gv_linear_timing_read",
                  "gv_linear_ln_blocks")
 
 
@@ -157,6 +168,9 @@ def _load():
     lib.gv_version.restype = C.c_int
     lib.gv_last_error.restype = C.c_char_p
     lib.gv_target.restype = C.c_char_p
+    lib.gv_act_format.restype = C.c_int
+    if lib.gv_act_format() != {"bf16": 0, "f16": 1}[ACT_FORMAT]:
+        raise ImportError(f"{LIB_PATH} was built for 16-bit format {lib.gv_act_format()} (0 = bf16, 1 = f16), GIPVIT_ACT_FORMAT asks for {ACT_FORMAT}")
     lib.gv_linear_workspace_bytes.restype = C.c_int64
     lib.gv_workspace_bytes.argtypes = [C.c_int32, vp]
     lib.gv_workspace_bytes.restype = C.c_int64

@@ -44,8 +44,7 @@ __device__ __forceinline__ bf16x8 read_nat(GV_LDS char* img, int row, int chunk)
 // transposed read: this lane addresses `row`, 16-column block dt, quarter p (0..3)
 __device__ __forceinline__ bf16x4 read_tr(GV_LDS char* img, int row, int dt, int p) {
     const int c16 = 2 * dt + (p >> 1);
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        (GV_LDS bf16x4*)(img + row * 128 + ((c16 ^ (row & 7)) << 4) + 8 * (p & 1)));
+    return GV_DS_READ_TR16(img + row * 128 + ((c16 ^ (row & 7)) << 4) + 8 * (p & 1));
 }
 __device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
@@ -55,7 +54,7 @@ template <int LO, int HI, class F>
 __device__ __forceinline__ void attn_static_for(F&& f) {
     if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); attn_static_for<LO + 1, HI>(f); }
 }
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) GV_MFMA_16x16x32((a), (b), (c))
 
 // ---------------------------------------------------------------------------------
 // forward
@@ -464,8 +463,8 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
                 const int k0 = ks * 32 + 4 * g + q4;
                 const bf16x8 ka = cat8(read_tr(Kimg, k0, dt, p4), read_tr(Kimg, k0 + 16, dt, p4));
                 const int hq = qt ^ (QH == 2 ? (k0 >> 1) & 3 : (k0 >> 2) & 1);          // same for key k0 + 16
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(dsT + k0 * DROW + (hq << 5) + p4 * 8));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(dsT + (k0 + 16) * DROW + (hq << 5) + p4 * 8));
+                const bf16x4 lo = GV_DS_READ_TR16((dsT + k0 * DROW + (hq << 5) + p4 * 8));
+                const bf16x4 hi = GV_DS_READ_TR16((dsT + (k0 + 16) * DROW + (hq << 5) + p4 * 8));
                 acc = MFMA16(ka, cat8(lo, hi), acc);
             }
             const int q = qc2 * 32 * QH + qt * 16 + li;

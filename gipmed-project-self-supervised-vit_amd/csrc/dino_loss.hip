@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int
         coef *= a.student_temp / a.hyper[GV_HYP_STUDENT_TEMP];
         a.teacher_temp = a.hyper[GV_HYP_TEACHER_TEMP]; a.student_temp = a.hyper[GV_HYP_STUDENT_TEMP];
     }
+    if (a.loss_scale) coef *= *a.loss_scale;
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int b0 = blockIdx.y * b_per, b1 = min(a.B, b0 + b_per);
     const int V = a.V, G = a.G, B = a.B, K = a.K;

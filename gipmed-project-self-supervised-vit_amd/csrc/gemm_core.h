@@ -172,8 +172,8 @@ __device__ __forceinline__ bf16x8 read_frag(GV_LDS char* tile, int blk16, int ks
         const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
         const int kr = ks * 32 + g * 8 + q;
         GV_LDS char* a0 = tile + kr * RB + ((blk16 ^ swz_t(kr)) << 5) + p * 8;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)a0);
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(a0 + 4 * RB));
+        bf16x4 lo = GV_DS_READ_TR16(a0);
+        bf16x4 hi = GV_DS_READ_TR16((a0 + 4 * RB));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
@@ -415,7 +415,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb[j], pa[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FN; ++j) acc[i][j] = GV_MFMA_16x16x32(pb[j], pa[i], acc[i][j]);
             };
             auto wait_young = [&](int young) {
                 if (young >= 2) wait_vmcnt<C::GLDS * 2>();
@@ -497,7 +497,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
                 for (int i = 0; i < FM; ++i) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = GV_MFMA_16x16x32(fb[ks][j], fa[ks][i], acc[i][j]);
                     if constexpr (C::SCHED == 3) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -519,7 +519,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
 #pragma unroll
                     for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
-                        for (int i = 0; i < FM; ++i) csum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[ks][i], csum[i], 0, 0, 0);
+                        for (int i = 0; i < FM; ++i) csum[i] = GV_MFMA_16x16x32(ones, fa[ks][i], csum[i]);
                 }
             }
             c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;

@@ -138,8 +138,8 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
         }
     }
     auto rd = [&](GV_LDS char* a0) {
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)a0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(a0 + 1024));
+        const bf16x4 lo = GV_DS_READ_TR16(a0);
+        const bf16x4 hi = GV_DS_READ_TR16((a0 + 1024));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
@@ -236,21 +236,21 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if constexpr (SWAP) acc[J][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[FA][ks][i], fb[FB][ks][j], acc[J][i][j], 0, 0, 0);
-                    else acc[J][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[FB][ks][j], fa[FA][ks][i], acc[J][i][j], 0, 0, 0);
+                    if constexpr (SWAP) acc[J][i][j] = GV_MFMA_16x16x32(fa[FA][ks][i], fb[FB][ks][j], acc[J][i][j]);
+                    else acc[J][i][j] = GV_MFMA_16x16x32(fb[FB][ks][j], fa[FA][ks][i], acc[J][i][j]);
                 }
         if (cs_on && cs_img == J) {
             if constexpr (SWAP) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) csum[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[FB][ks][j], csum[j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) csum[j] = GV_MFMA_16x16x32(ones, fb[FB][ks][j], csum[j]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (wn == i) {
 #pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) csum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[FA][ks][i], csum[0], 0, 0, 0);
+                        for (int ks = 0; ks < 2; ++ks) csum[0] = GV_MFMA_16x16x32(ones, fa[FA][ks][i], csum[0]);
                     }
             }
         }

@@ -6,15 +6,33 @@
 #include <stdarg.h>
 #include "../../include/gipvit.h"
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// The library's 16-bit operand / activation format is a BUILD property (gv_act_format()): bfloat16 in libgipvit_hip.so, IEEE half
+// in libgipvit_hip_f16.so (-DGV_ACT_F16: the reference's --amp --amp-dtype float16 arithmetic, train.py:452-465).  The kernels are
+// written once against these names; "bf16" in identifiers and comments below reads "the 16-bit format of this build".
+#ifdef GV_ACT_F16
+#define GV_A16 _Float16
+#define GV_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
+#define GV_A16 __bf16
+#define GV_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
+typedef GV_A16 bf16;
+typedef __attribute__((ext_vector_type(2))) GV_A16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) GV_A16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) GV_A16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define GV_LDS __attribute__((address_space(3)))
 #define GV_GLOBAL __attribute__((address_space(1)))
+
+// ds_read_b64_tr_b16: the transposing LDS read moves 16-bit patterns, whatever they encode
+#ifdef GV_ACT_F16
+typedef __attribute__((ext_vector_type(4))) short gv_i16x4;
+#define GV_DS_READ_TR16(p) __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((GV_LDS gv_i16x4*)(p)))
+#else
+#define GV_DS_READ_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((GV_LDS bf16x4*)(p))
+#endif
 
 // ---- error plumbing (never throws across the ABI) -------------------------
 void gv_set_error(const char* fmt, ...);

@@ -14,8 +14,15 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
         a.teacher_momentum = a.hyper[GV_HYP_TEACHER_MOM]; a.grad_scale = a.hyper[GV_HYP_GRAD_SCALE];
     }
     float gscale = a.grad_scale;
-    if (a.clip_norm > 0.f) {
-        const float nrm = sqrtf(*a.gnorm_sq) * fabsf(a.grad_scale);
+    if (a.loss_scale) {                                    // fp16 loss scaling: unscale; a non-finite gradient skips the step
+        gscale /= a.loss_scale[0];
+        if (!isfinite(*a.gnorm_sq)) a.mode = 3;
+        // a skipped step is no optimizer step: Adam's bias corrections count the APPLIED steps (state[3]), not the host's calls
+        const float t = a.loss_scale[3] + 1.0f;
+        a.bias_corr1 = 1.0f - powf(a.beta1, t); a.bias_corr2 = 1.0f - powf(a.beta2, t);
+    }
+    if (a.clip_norm > 0.f && a.mode != 3) {
+        const float nrm = sqrtf(*a.gnorm_sq) * fabsf(gscale);
         const float c = a.clip_norm / (nrm + 1e-6f);
         if (c < 1.0f) gscale *= c;
     }
@@ -25,7 +32,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
     const float om = 1.0f - a.teacher_momentum;
     const long n4 = a.n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4 g = ((const f32x4*)a.grad)[i] * gscale;
+        f32x4 g = a.mode == 3 ? f32x4{0.f, 0.f, 0.f, 0.f} : ((const f32x4*)a.grad)[i] * gscale;
         if (a.clip_value > 0.f) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = fminf(fmaxf(g[j], -a.clip_value), a.clip_value);
@@ -56,6 +63,16 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(gv_adamw_ema_args a) {
             if (a.teacher_bf16) ((bf16x4*)a.teacher_bf16)[i] = bf16x4{(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
         }
     }
+}
+
+__global__ void loss_scale_update_kernel(gv_loss_scale_update_args a) {
+    float S = a.state[0], good = a.state[1];
+    if (!isfinite(*a.gnorm_sq)) { S *= a.backoff_factor; good = 0.f; a.state[2] += 1.f; }
+    else {
+        a.state[3] += 1.f;
+        if (++good >= (float)a.growth_interval) { S *= a.growth_factor; good = 0.f; }
+    }
+    a.state[0] = S; a.state[1] = good;
 }
 
 // adaptive gradient clipping: one wave per unit (include/gipvit.h gv_agc)
@@ -129,6 +146,15 @@ __global__ __launch_bounds__(256) void lamb_kernel(gv_lamb_args a) {
 
 }  // namespace
 
+extern "C" int gv_loss_scale_update(const gv_loss_scale_update_args* a, void* stream) {
+    GV_REQUIRE(a && a->state && a->gnorm_sq, GV_E_NULL, "gv_loss_scale_update: null pointer");
+    GV_REQUIRE(a->growth_factor >= 1.f && a->backoff_factor > 0.f && a->backoff_factor <= 1.f && a->growth_interval > 0, GV_E_SHAPE,
+               "gv_loss_scale_update: need growth_factor >= 1, 0 < backoff_factor <= 1, growth_interval > 0");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *a);
+    GV_LAUNCH_CHECK("gv_loss_scale_update");
+    return GV_OK;
+}
+
 extern "C" int gv_agc(const gv_agc_args* a, void* stream) {
     GV_REQUIRE(a && a->p && a->grad && a->units, GV_E_NULL, "gv_agc: null pointer");
     GV_REQUIRE(a->n_units > 0 && a->clip_factor > 0.f && a->eps > 0.f, GV_E_SHAPE, "gv_agc: need n_units > 0, clip_factor > 0, eps > 0");
@@ -156,6 +182,7 @@ extern "C" int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream) {
     GV_REQUIRE(gv_aligned(a->p, 16) && gv_aligned(a->grad, 16) && gv_aligned(a->m, 16) && gv_aligned(a->v, 16), GV_E_ALIGN,
                "gv_adamw_ema: buffers must be 16-byte aligned");
     if (a->clip_norm > 0.f) GV_REQUIRE(a->gnorm_sq, GV_E_NULL, "gv_adamw_ema: clip_norm needs gnorm_sq");
+    if (a->loss_scale) GV_REQUIRE(a->gnorm_sq, GV_E_NULL, "gv_adamw_ema: loss_scale needs gnorm_sq (the finite check)");
     GV_REQUIRE(!(a->clip_norm > 0.f && a->clip_value > 0.f), GV_E_UNSUPPORTED, "gv_adamw_ema: clip_norm and clip_value exclude each other (--clip-mode norm | value)");
     if (!a->hyper) GV_REQUIRE(a->bias_corr1 > 0.f && a->bias_corr2 > 0.f, GV_E_SHAPE, "gv_adamw_ema: bias corrections must be > 0");
     long blocks = (a->n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096;

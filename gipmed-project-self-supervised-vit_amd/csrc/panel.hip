@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
                 for (int i = 0; i < FMH; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc8[J][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc8[J][i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc8[J][i][j] = GV_MFMA_16x16x32(fb[ks][j], fa[ks][i], acc8[J][i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NF; ++j) acc[i][j] = GV_MFMA_16x16x32(fw[j], fa[i], acc[i][j]);
         }
     }
     // ---- MODE_WIDE epilogue: PER WAVE, no workgroup barrier between its two ends.  A wave owns, of every 16-row fragment of

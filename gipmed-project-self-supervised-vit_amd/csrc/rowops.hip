@@ -235,7 +235,8 @@ __global__ void softmax_lsce_kernel(gv_softmax_lsce_args a) {
         // dl/dp_c = q_c - [(1-s) 1{c=t} + s/C]
         float dot = 0.f;
         for (int c = 0; c < C; ++c) { w[c] = q[c] - ((c == t ? 1.0f - sm : 0.f) + sm / C); dot += w[c] * p[c]; }
-        for (int c = 0; c < C; ++c) a.dlogits[(long)b * C + c] = p[c] * (w[c] - dot) / a.B;
+        const float gs = (a.loss_scale ? *a.loss_scale : 1.0f) / a.B;
+        for (int c = 0; c < C; ++c) a.dlogits[(long)b * C + c] = p[c] * (w[c] - dot) * gs;
         if (a.prob) for (int c = 0; c < C; ++c) a.prob[(long)b * C + c] = p[c];
     }
     red[threadIdx.x] = l;

@@ -31,7 +31,7 @@ import torch
 from . import _lib as L
 from . import ops
 
-bf16, f32 = torch.bfloat16, torch.float32
+bf16, f32 = ops.bf16, torch.float32      # ops.bf16: the 16-bit dtype of the loaded library build (float16 under GIPVIT_ACT_FORMAT=f16)
 
 ARCHS = {   # vit.pyc@L275-293
     "vit_tiny": dict(embed_dim=192, depth=12, num_heads=3),
@@ -697,6 +697,8 @@ class DinoEngine:
         act = f32 if fp32 else bf16
         self.precision = precision
         dev = torch.device(device)
+        # the float16 library build (--amp --amp-dtype float16) trains under dynamic loss scaling: torch's GradScaler on the device
+        self.scaler = ops.LossScaler(dev) if (L.ACT_FORMAT == "f16" and not fp32) else None
         self.dev, self.arch, self.B, self.tile = dev, arch, batch, tile
         D = ARCHS[arch]["embed_dim"]
         self.D, self.K, self.G, self.V = D, out_dim, n_global, n_global + n_local
@@ -868,7 +870,8 @@ class DinoEngine:
         if t_side is not None:
             main.wait_event(self._ev_join)
         ops.dino_loss(self.hb_s.logits, self.hb_t.logits, self.center, self.hb_s.dlogits, self.loss, self.center_sum,
-                      self.loss_ws, B, V, G, self.K, self.ts, self.tt, hyper=self.hyper)
+                      self.loss_ws, B, V, G, self.K, self.ts, self.tt, hyper=self.hyper,
+                      loss_scale=self.scaler.scale if self.scaler is not None else None)
         if mn > 1:
             if first:
                 self._loss_acc, self._center_acc = self.loss.clone(), self.center_sum.clone()
@@ -912,11 +915,13 @@ class DinoEngine:
     def optimizer_step(self):
         a = self.arena
         by_norm = self.clip > 0 and self.clip_mode == "norm"
-        if by_norm:
+        scaled = self.scaler is not None
+        if by_norm or scaled:           # loss scaling: the sum of squares is also the finite check of GradScaler.step()
             ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
         kw = dict(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=max(self.t, 1),
-                  clip_norm=self.clip if by_norm else 0.0, gnorm_sq=self.gnorm_sq if by_norm else None, hyper=self.hyper,
-                  clip_value=self.clip if (self.clip > 0 and self.clip_mode == "value") else 0.0)
+                  clip_norm=self.clip if by_norm else 0.0, gnorm_sq=self.gnorm_sq if (by_norm or scaled) else None, hyper=self.hyper,
+                  clip_value=self.clip if (self.clip > 0 and self.clip_mode == "value") else 0.0,
+                  loss_scale=self.scaler.scale if scaled else None)
         lo = 0
         if not self.train_last_layer:
             # the head's last layer is frozen for the first epochs (DINO cancel_gradients_last_layer sets its grad to
@@ -932,6 +937,8 @@ class DinoEngine:
         if a.n > a.n_decay:   # biases / LN / pos / cls: same schedules, weight-decay multiplier 0
             sl = slice(a.n_decay, a.n)
             ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], a.t[sl], a.tb[sl], a.n - a.n_decay, weight_decay=0.0, **kw)
+        if scaled:
+            self.scaler.update(self.gnorm_sq)
         self._refresh_wn()
         ops.center_update(self.center, self.center_sum, self.K, self.cm, 1.0 / (self.G * self.B * self.reducer.world * self._n_micro))
 
@@ -986,6 +993,11 @@ class SupervisedEngine:
         act = f32 if fp32 else bf16
         self.precision = precision
         dev = torch.device(device)
+        # float16 library build: dynamic loss scaling (torch GradScaler via timm NativeScaler, reference train.py:585-602, 1061-1070)
+        self.scaler = ops.LossScaler(dev) if (L.ACT_FORMAT == "f16" and not fp32) else None
+        if self.scaler is not None and (opt == "lamb" or clip_mode == "agc"):
+            raise ValueError("float16 loss scaling is built for adamw / adam / sgd with --clip-mode norm | value; "
+                             "--opt lamb and --clip-mode agc run with --amp-dtype bfloat16")
         self.dev, self.arch, self.B, self.img, self.C = dev, arch, batch, img_size, num_classes
         D = ARCHS[arch]["embed_dim"]
         self.D = D
@@ -1070,7 +1082,8 @@ class SupervisedEngine:
         B, C, D, W = self.B, self.C, self.D, self.W
         self.arena.g.zero_()
         self.forward(tiles_u8, fill=fill)
-        ops.softmax_lsce(self.logits, target.view(-1), self.loss, self.dlogits, self.prob, B, C, self.smoothing)
+        ops.softmax_lsce(self.logits, target.view(-1), self.loss, self.dlogits, self.prob, B, C, self.smoothing,
+                         loss_scale=self.scaler.scale if self.scaler is not None else None)
         # head backward: dW = dlogits^T f, db = colsum(dlogits), df = dlogits W
         ops.small_matmul(self.dlogits, self.feats, W.g("head.weight"), C, D, B, sam=1, sak=C, sbk=D, sbn=1, accumulate=True)
         ops.small_matmul(self.ones, self.dlogits, W.g("head.bias").view(1, C), 1, C, B, sam=0, sak=1, sbk=C, sbn=1, accumulate=True)
@@ -1086,12 +1099,15 @@ class SupervisedEngine:
         by_norm = self.clip > 0 and self.clip_mode == "norm"
         if self.clip > 0 and self.clip_mode == "agc":
             ops.agc(a.p, a.g, self._agc_units, self.clip, 1e-3, 1.0 / self.reducer.world)
-        if by_norm:
+        scaled = self.scaler is not None
+        if by_norm or scaled:
             ops.sumsq(a.g, self.red_ws, self.gnorm_sq)
         kw = dict(lr=self.lr if lr is None else lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=self.t,
-                  grad_scale=1.0 / self.reducer.world, clip_norm=self.clip if by_norm else 0.0, gnorm_sq=self.gnorm_sq if by_norm else None,
+                  grad_scale=1.0 / self.reducer.world, clip_norm=self.clip if by_norm else 0.0,
+                  gnorm_sq=self.gnorm_sq if (by_norm or scaled) else None,
                   mode=self.opt_mode, teacher_momentum=self.ema_decay or 0.0,
-                  clip_value=self.clip if (self.clip > 0 and self.clip_mode == "value") else 0.0)
+                  clip_value=self.clip if (self.clip > 0 and self.clip_mode == "value") else 0.0,
+                  loss_scale=self.scaler.scale if scaled else None)
         tt = (lambda sl: (a.t[sl], a.tb[sl])) if a.t is not None else (lambda sl: (None, None))
         if self.opt_mode < 0:
             if not self.train_backbone:
@@ -1115,6 +1131,8 @@ class SupervisedEngine:
         for lo, hi, wd in ranges:
             sl = slice(lo, hi)
             ops.adamw_ema(a.p[sl], a.g[sl], a.m[sl], a.v[sl], a.pb[sl], *tt(sl), hi - lo, weight_decay=wd, **kw)
+        if scaled:
+            self.scaler.update(self.gnorm_sq)
 
     def step(self, tiles_u8, target, lr=None, fill=None):
         assert tiles_u8.dtype == torch.uint8 and target.dtype == torch.int64

@@ -9,7 +9,9 @@ import torch
 
 from . import _lib as L
 
-bf16, f32 = torch.bfloat16, torch.float32
+# the 16-bit tensor dtype of this process's library build (_lib.ACT_FORMAT): bfloat16 by default, float16 for the -DGV_ACT_F16
+# library (--amp --amp-dtype float16); the name follows the default build
+bf16, f32 = (torch.bfloat16 if L.ACT_FORMAT == "bf16" else torch.float16), torch.float32
 
 
 def _stream() -> int:
@@ -242,7 +244,7 @@ def attention_fwd_varlen(qkv, o, segments, H: int, scale: float):
     """All segments of a token-concatenated row space in one call: ``segments`` = [(n_img, N, lse f32 [n_img, H, N]), ...] in row
     order; qkv [T, 3 H 64], o [T, H 64].  bf16: gv_attention_fwd_varlen (a long + a short segment share ONE launch); the fp32
     operand mode runs one call per segment."""
-    if qkv.dtype != torch.bfloat16 or len(segments) > L.GV_ATTN_MAX_SEG:
+    if qkv.dtype != bf16 or len(segments) > L.GV_ATTN_MAX_SEG:
         row = 0
         for n_img, N, lse in segments:
             attention_fwd(qkv[row:row + n_img * N], n_img, N, H, scale, o=o[row:row + n_img * N], lse=lse)
@@ -311,9 +313,11 @@ def weightnorm_bwd(dw, v, g, dv, dg, rows: int, C: int, accumulate: bool):
 
 
 def dino_loss(student, teacher, center, dstudent, loss, center_sum, workspace, B: int, V: int, G: int, K: int,
-              student_temp: float, teacher_temp: float, grad_scale: float = 1.0, hyper=None):
+              student_temp: float, teacher_temp: float, grad_scale: float = 1.0, hyper=None, loss_scale=None):
+    """``loss_scale``: device f32 scalar (LossScaler.state) that multiplies the gradient -- fp16 loss scaling."""
     a = L.gv_dino_loss_args(student.data_ptr(), teacher.data_ptr(), center.data_ptr(), dstudent.data_ptr(), loss.data_ptr(),
-                            center_sum.data_ptr(), workspace.data_ptr(), B, V, G, K, student_temp, teacher_temp, grad_scale, _p(hyper))
+                            center_sum.data_ptr(), workspace.data_ptr(), B, V, G, K, student_temp, teacher_temp, grad_scale, _p(hyper),
+                            _p(loss_scale))
     L.call("gv_dino_loss" + _sfx(dstudent), a, _stream())
 
 
@@ -321,8 +325,9 @@ def center_update(center, center_sum, K: int, momentum: float, inv_rows: float):
     L.call("gv_center_update", L.gv_center_update_args(center.data_ptr(), center_sum.data_ptr(), K, momentum, inv_rows), _stream())
 
 
-def softmax_lsce(logits, target, loss, dlogits, prob, B: int, C: int, smoothing: float):
-    a = L.gv_softmax_lsce_args(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), dlogits.data_ptr(), _p(prob), B, C, smoothing)
+def softmax_lsce(logits, target, loss, dlogits, prob, B: int, C: int, smoothing: float, loss_scale=None):
+    a = L.gv_softmax_lsce_args(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), dlogits.data_ptr(), _p(prob), B, C, smoothing,
+                               _p(loss_scale))
     L.call("gv_softmax_lsce", a, _stream())
 
 
@@ -349,11 +354,42 @@ def sumsq(x, workspace, out, accumulate: bool = False, n: Optional[int] = None):
 
 
 def adamw_ema(p, grad, m, v, p_bf16, teacher, teacher_bf16, n: int, *, lr, beta1, beta2, eps, weight_decay, step: int,
-              grad_scale=1.0, clip_norm=0.0, gnorm_sq=None, teacher_momentum=0.0, hyper=None, mode=0, clip_value=0.0):
+              grad_scale=1.0, clip_norm=0.0, gnorm_sq=None, teacher_momentum=0.0, hyper=None, mode=0, clip_value=0.0, loss_scale=None):
+    """``loss_scale``: device f32 scalar S; the gradient is divided by it and a non-finite ``gnorm_sq`` skips the update (GradScaler.step)."""
     a = L.gv_adamw_ema_args(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), _p(teacher), _p(teacher_bf16), n,
                             lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
-                            grad_scale, clip_norm, _p(gnorm_sq), teacher_momentum, _p(hyper), mode, clip_value)
+                            grad_scale, clip_norm, _p(gnorm_sq), teacher_momentum, _p(hyper), mode, clip_value, _p(loss_scale))
     L.call("gv_adamw_ema", a, _stream())
+
+
+class LossScaler:
+    """torch.cuda.amp.GradScaler as timm's NativeScaler drives it (reference train.py:585-602, 1061-1070), kept on the device:
+    ``state`` = f32 [S, consecutive finite steps, skipped steps, applied steps].  The loss kernels multiply their gradient by S, gv_adamw_ema divides
+    it out and skips the update when the gradient's sum of squares is not finite, ``update`` is GradScaler.update().  Nothing comes
+    back to the host; ``state_dict`` (checkpoints: timm's 'amp_scaler' entry) synchronises."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=f32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    @property
+    def scale(self):        # what the kernels take: the loss kernels read [0], gv_adamw_ema [0] and [3]
+        return self.state
+
+    def update(self, gnorm_sq):
+        a = L.gv_loss_scale_update_args(self.state.data_ptr(), gnorm_sq.data_ptr(), self.growth_factor, self.backoff_factor, self.growth_interval)
+        L.call("gv_loss_scale_update", a, _stream())
+
+    def state_dict(self):
+        s = self.state.tolist()
+        return {"scale": s[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(s[1]), "skipped_steps": int(s[2]), "applied_steps": int(s[3])}
+
+    def load_state_dict(self, d):
+        self.growth_factor, self.backoff_factor = float(d["growth_factor"]), float(d["backoff_factor"])
+        self.growth_interval = int(d["growth_interval"])
+        self.state.copy_(torch.tensor([float(d["scale"]), float(d["_growth_tracker"]), float(d.get("skipped_steps", 0)),
+                                       float(d.get("applied_steps", 0))], dtype=f32))
 
 
 def lamb_block_table(tensors, chunk: int = 1 << 16) -> torch.Tensor:

@@ -16,7 +16,9 @@
  *     synchronises, so every call is hipGraph-capturable;
  *   - return 0 on success, <0 = GV_E_* argument error (message in
  *     gv_last_error(), thread local), >0 = hipError_t of a failed launch;
- *   - "bf16" buffers hold bfloat16 bit patterns (uint16_t), "f32" IEEE float;
+ *   - "bf16" buffers hold the library build's 16-bit format (uint16_t patterns): bfloat16 in libgipvit_hip.so, IEEE
+ *     half in libgipvit_hip_f16.so -- the same sources built with -DGV_ACT_F16 for the reference's
+ *     --amp --amp-dtype float16 (train.py:452-465); gv_act_format() says which.  "f32" is IEEE float;
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
  */
 #ifndef GIPVIT_H
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 7
+#define GV_ABI_VERSION 8
 enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
        GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
@@ -45,6 +47,9 @@ int gv_version(void);
 const char* gv_last_error(void);
 /* name of the gfx target the kernels were compiled for ("gfx950") */
 const char* gv_target(void);
+/* the 16-bit operand / activation format this library was built for */
+enum { GV_ACT_FORMAT_BF16 = 0, GV_ACT_FORMAT_F16 = 1 };
+int gv_act_format(void);
 
 /* ---- patchify: replaces PatchEmbed's Conv2d im2col on the reference input
  * contract (vit.pyc@L167-170; datasets.py:614-631 -> transformations.py:124-128
@@ -423,6 +428,7 @@ typedef struct {
     int32_t B, V, G, K;
     float student_temp, teacher_temp, grad_scale;
     const float* hyper;   /* optional device vector (see gv_adamw_ema_args): temps */
+    const float* loss_scale; /* optional DEVICE scalar: dstudent is multiplied by it (fp16 loss scaling, gv_loss_scale_update) */
 } gv_dino_loss_args;
 int gv_dino_loss(const gv_dino_loss_args* a, void* stream);
 
@@ -436,6 +442,7 @@ int gv_center_update(const gv_center_update_args* a, void* stream);
 typedef struct {
     const float* logits; const int64_t* target; float* loss; float* dlogits; float* prob;
     int32_t B, C; float smoothing;
+    const float* loss_scale; /* optional DEVICE scalar: dlogits is multiplied by it (fp16 loss scaling); the loss itself is not */
 } gv_softmax_lsce_args;
 int gv_softmax_lsce(const gv_softmax_lsce_args* a, void* stream);
 
@@ -485,8 +492,28 @@ typedef struct {
     /* > 0: every gradient element (after grad_scale) is clamped to [-clip_value, clip_value] -- `--clip-mode value`,
      * torch.nn.utils.clip_grad_value_ (reference train.py:1072-1077 dispatch_clip_grad); use instead of clip_norm */
     float clip_value;
+    /* optional: the DEVICE state vector of gv_loss_scale_update, [S, .., .., applied steps] (fp16 loss scaling,
+     * torch.cuda.amp.GradScaler as driven by timm's NativeScaler: reference train.py:585-602, 1061-1070).  The gradient was
+     * produced from S * loss, so g = grad * grad_scale / S (the clip norm is that of the unscaled gradient); when *gnorm_sq
+     * (required then) is not finite the call leaves p, m, v untouched -- GradScaler.step() skips optimizer.step() -- while the
+     * teacher / --model-ema update and the 16-bit refresh still run; and Adam's bias corrections are taken at step
+     * state[3] + 1 (the optimizer's own count of applied steps) instead of the by-value / hyper ones.                        */
+    const float* loss_scale;
 } gv_adamw_ema_args;
 int gv_adamw_ema(const gv_adamw_ema_args* a, void* stream);
+
+/* ---- GradScaler.update() (torch.cuda.amp.GradScaler: init_scale 65536, growth_factor 2, backoff_factor 0.5, growth_interval
+ * 2000): state[0] = S, state[1] = number of consecutive finite steps, state[2] = number of skipped steps so far (for the log),
+ * state[3] = number of applied optimizer steps.
+ * *gnorm_sq = sum of squares of the scaled gradient arena (after the data-parallel all-reduce, so every rank decides alike):
+ *   not finite:  S *= backoff_factor, state[1] = 0, state[2] += 1
+ *   finite:      state[3] += 1;  if ++state[1] == growth_interval: S *= growth_factor, state[1] = 0
+ * One thread, stream-ordered behind the optimizer launches that read S; nothing returns to the host.                         */
+typedef struct {
+    float* state; const float* gnorm_sq;
+    float growth_factor, backoff_factor; int32_t growth_interval;
+} gv_loss_scale_update_args;
+int gv_loss_scale_update(const gv_loss_scale_update_args* a, void* stream);
 
 /* ---- dropout (`--drop`, reference train.py:283-284 -> create_model(drop_rate): nn.Dropout after the pos-embed add, after attn.proj,
  * after the MLP activation and after mlp.fc2; vit.pyc@L98-104, L119-131, L235-246).  Counter-based masks, so that the backward

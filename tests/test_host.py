@@ -22,7 +22,23 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), f"{name} declared in gipvit.h but not exported"
     bound = set(_lib.ENTRY_POINTS) | set(_lib.PLAIN_SYMBOLS)
     assert declared == bound, (declared - bound, bound - declared)
-    assert _lib.lib.gv_version() == 7 and _lib.lib.gv_target() == b"gfx950"
+    assert _lib.lib.gv_version() == 8 and _lib.lib.gv_target() == b"gfx950" and _lib.lib.gv_act_format() == 0
+    # the float16 build (-DGV_ACT_F16, --amp --amp-dtype float16) is the same ABI
+    f16 = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libgipvit_hip_f16.so"))
+    for name in declared:
+        assert hasattr(f16, name), f"{name} missing from libgipvit_hip_f16.so"
+    assert f16.gv_version() == 8 and f16.gv_act_format() == 1
+
+
+def test_act_format_selects_the_library_build():
+    """GIPVIT_ACT_FORMAT=f16 loads libgipvit_hip_f16.so and makes float16 the 16-bit tensor dtype; a mismatch is an ImportError."""
+    code = ("import sys; sys.path.insert(0, %r); from gipvit import _lib, ops; "
+            "print(_lib.lib.gv_act_format(), ops.bf16, _lib.LIB_PATH.endswith('libgipvit_hip_f16.so'))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GIPVIT_ACT_FORMAT="f16"), capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["1", "torch.float16", "True"], (r.stdout, r.stderr[-400:])
+    from gipvit import _lib
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GIPVIT_ACT_FORMAT="f16", GIPVIT_LIB=_lib.LIB_PATH), capture_output=True, text=True)
+    assert r.returncode != 0 and "built for 16-bit format 0" in r.stderr
 
 
 def test_struct_layout_matches_header():
@@ -330,10 +346,18 @@ def test_every_used_flag_is_read_by_the_driver():
     assert a.opt == "adamw" and train.check_supported(a, lambda m: None) is None
     a, _ = train.parse_args(["--model", "vit_tiny"])
     assert a.opt == "sgd"
-    # --amp-dtype float16 is not silently bf16: it is announced (fp16 autocast + loss scaling is not built)
-    msgs = []
-    a, _ = train.parse_args(["--model", "vit_tiny", "--amp", "--amp-dtype", "float16"]); train.check_supported(a, msgs.append)
-    assert any("fp16" in m for m in msgs)
+    # every accepted value of --amp-dtype selects its own arithmetic: float16 (the reference default) = the float16 build of the
+    # library + dynamic loss scaling, bfloat16 = the default build; anything else, and the pairings the scaler is not built for, raise
+    a, _ = train.parse_args(["--model", "vit_tiny", "--amp"])
+    assert a.amp_dtype == "float16" and train.amp_is_f16(a) and train.check_supported(a, lambda m: None) is None
+    a, _ = train.parse_args(["--model", "vit_tiny", "--amp", "--amp-dtype", "bfloat16"])
+    assert not train.amp_is_f16(a)
+    a, _ = train.parse_args(["--model", "vit_tiny", "--amp-dtype", "float16"])
+    assert not train.amp_is_f16(a)                                                     # without --amp the dtype is not consulted (train.py:452-465)
+    for bad in (["--amp", "--amp-dtype", "float8"], ["--amp", "--opt", "lamb"], ["--amp", "--clip-mode", "agc", "--clip-grad", "0.1"]):
+        a, _ = train.parse_args(["--model", "vit_tiny"] + bad)
+        with pytest.raises(SystemExit):
+            train.check_supported(a, lambda m: None)
     # --drop-path draws (gipvit.droppath): block 0 never drops, factors are 0 or 1 / keep, expectation 1
     import numpy as np
     from gipvit.droppath import DropPathSampler

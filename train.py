@@ -161,9 +161,13 @@ def check_supported(args, log=_logger.warning):
         if c != 3 or h != w or h % 16:
             raise SystemExit(f"--input-size {args.input_size}: need 3 x S x S with S a multiple of 16")
         img = h
-    if args.amp and args.amp_dtype not in ("bfloat16", "bf16"):
-        log(f"--amp --amp-dtype {args.amp_dtype}: fp16 autocast + loss scaling (train.py:452-465, 585-602) is not built; this build's "
-            "GEMMs always take bf16 operands with f32 accumulation and f32 master weights (the --amp-dtype bfloat16 arithmetic)")
+    if args.amp and args.amp_dtype.lower() not in ("float16", "fp16", "bfloat16", "bf16"):
+        raise SystemExit(f"--amp-dtype {args.amp_dtype}: 'float16' (the reference default, train.py:332) or 'bfloat16'")
+    if amp_is_f16(args):
+        # the same kernels built with IEEE half as the 16-bit format (libgipvit_hip_f16.so) + torch's GradScaler on the device
+        if args.opt.lower() == "lamb" or args.clip_mode == "agc":
+            raise SystemExit("--amp --amp-dtype float16: dynamic loss scaling is built for adamw / adam / sgd with --clip-mode norm | value; "
+                             "run --opt lamb / --clip-mode agc with --amp-dtype bfloat16")
     elif not args.amp and args.precision != "fp32":
         log("no --amp: the reference would compute in fp32 (train.py:452-465); this build's GEMMs take bf16 operands with f32 "
             "accumulation, f32 residual stream and f32 master weights (the --amp --amp-dtype bfloat16 arithmetic) unless "
@@ -175,6 +179,11 @@ def check_supported(args, log=_logger.warning):
     if args.supervised and args.dino:
         raise SystemExit("--supervised (fine-tune with labels, train.py:715-717) and --dino (self-supervised) exclude each other")
     return img
+
+
+def amp_is_f16(args) -> bool:
+    """``--amp`` with the reference's default ``--amp-dtype float16`` (train.py:332, 452-465)."""
+    return bool(args.amp) and args.amp_dtype.lower() in ("float16", "fp16")
 
 
 class Meter:
@@ -210,6 +219,10 @@ def main(argv=None):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", args.local_rank))
     primary = rank == 0
     img_from_input_size = check_supported(args, _logger.warning if primary else (lambda m: None))
+    if amp_is_f16(args):
+        # one process computes in one 16-bit format: pick the float16 build of the library before it is first loaded
+        assert "gipvit._lib" not in sys.modules, "the library was loaded before the --amp-dtype was known"
+        os.environ["GIPVIT_ACT_FORMAT"] = "f16"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     reducer = None
@@ -323,6 +336,9 @@ def main(argv=None):
             eng.load_state(sd, strip(ck["state_dict_ema"]) if (ema_decay is not None and "state_dict_ema" in ck) else None)
         if "optimizer" in ck and not args.no_resume_opt:
             eng.arena.m.copy_(ck["optimizer"]["exp_avg"]); eng.arena.v.copy_(ck["optimizer"]["exp_avg_sq"]); eng.t = int(ck["optimizer"]["step"])
+        if eng.scaler is not None and isinstance(ck.get("amp_scaler"), dict):      # timm resume_checkpoint(..., loss_scaler=...)
+            # (a GradScaler state written by torch itself has no count of applied steps: the optimizer's step count stands in)
+            eng.scaler.load_state_dict(dict({"applied_steps": eng.t}, **ck["amp_scaler"]))
         start_epoch = args.start_epoch if args.start_epoch is not None else ck.get("epoch", -1) + 1
     if hasattr(source, "epoch"):
         source.epoch = start_epoch                 # the synthetic source seeds every epoch: a resumed run sees epoch k's tiles
@@ -378,6 +394,8 @@ def main(argv=None):
             ex["state_dict_ema"] = eng.state_dict(ema=True)     # timm CheckpointSaver key
         if drop_sampler is not None:
             ex["drop_path_rng"] = drop_sampler.state_dict()     # a resumed run continues the mask stream
+        if eng.scaler is not None:
+            ex["amp_scaler"] = eng.scaler.state_dict()          # timm CheckpointSaver(amp_scaler=loss_scaler) key, train.py:585-602
         return ex
 
     # the step's critical path runs on a high-priority stream; the engine's side stream (teacher forward,
