@@ -149,8 +149,9 @@ def main():
                     "the fixed parity windows of SURVEY 8(d); the default (and the quoted metric) uses the fixed windows")
     ap.add_argument("--view-augment", action="store_true", help="with --random-crops: per-crop colour jitter / grayscale / blur / solarisation in the "
                     "pass that cuts the crops (gv_crop_augment)")
-    ap.add_argument("--precision", default="bf16", choices=("bf16", "fp32"), help="fp32: the verification mode (every operand f32, csrc/f32path.hip); "
-                    "the headline number is the bf16 training path")
+    ap.add_argument("--precision", default="bf16", choices=("bf16", "f16", "fp32"), help="fp32: the verification mode (every operand f32, "
+                    "csrc/f32path.hip); f16: the float16 build of the library under dynamic loss scaling (train.py --amp, the reference's default "
+                    "--amp-dtype); the headline number is the bf16 training path")
     ap.add_argument("--trace-loss", action="store_true", help="debug: synchronise and print the loss after every step")
     args = ap.parse_args()
 
@@ -188,13 +189,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if args.precision == "f16":          # one process computes in one 16-bit format: chosen before the library is first loaded
+        os.environ["GIPVIT_ACT_FORMAT"] = "f16"
     from gipvit.engine import DinoEngine
     from gipvit import roofline
     n_local = 8 if args.config == "c3" else 0
     # DINO recipe (paper defaults): AdamW, lr = 5e-4 * global_batch / 256, wd 0.04, clip 3.0
     lr = 5e-4 * args.batch * world / 256.0
     eng = DinoEngine(arch=args.arch, img_size=224, out_dim=65536, batch=args.batch, n_local=n_local, lr=lr, weight_decay=0.04,
-                     clip_grad=3.0, device=dev, reducer=reducer, precision=args.precision)
+                     clip_grad=3.0, device=dev, reducer=reducer, precision="fp32" if args.precision == "fp32" else "bf16")
     from gipvit.models import init_vit_state, init_dino_head_state
     eng.load_state(init_vit_state(args.arch, 224, 0, seed=0), init_dino_head_state(eng.D, 65536, seed=1))
     tiles = synth_tiles(args.batch, 256, 1234 + rank, dev)
@@ -261,7 +264,7 @@ def main():
             "metric": "tiles/sec/GPU ViT-S/16 DINO (2g+8l crops, 256px) at 1/2/4/8 MI355X",
             "value": round(tiles_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic", "rccl_ranks": rccl_ranks,
+            "dtype": {"fp32": "f32", "f16": "f16", "bf16": "bf16"}[args.precision], "data": "synthetic", "rccl_ranks": rccl_ranks,
             "config": {"workload": f"{args.arch}/16 DINO 2x224+{n_local}x96 crops of 256px NHWC u8 tiles, K=65536 ({args.config})",
                        "tiles_per_gpu": args.batch * args.micro, "micro_batches": args.micro, "global_tiles": args.batch * args.micro * world, "parallelism": f"dp{world}",
                        "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops), "view_augment": bool(args.view_augment and args.random_crops)},
