@@ -48,3 +48,13 @@ def test_train_amp_float16(dev, tmp_path):
     out = _run(common + ["--epochs", "2", "--experiment", "h16r", "--amp", "--resume", str(tmp_path / "h16" / "last.pth.tar")])
     ck2 = torch.load(tmp_path / "h16r" / "last.pth.tar", weights_only=True)
     assert ck2["amp_scaler"]["applied_steps"] + ck2["amp_scaler"]["skipped_steps"] == 12 and ck2["epoch"] == 1
+    # the self-supervised step under the same flag: student + teacher + centre train, the scaler state rides in the checkpoint
+    dino = [sys.executable, os.path.join(ROOT, "train.py"), "--dino", "--model", "vit_tiny", "--dataset", "synthetic", "-b", "2", "--out-dim", "1024",
+            "--batches-per-epoch", "4", "--lr", "1e-4", "--epochs", "1", "--log-interval", "1", "--output", str(tmp_path), "--seed", "7", "--no-validate",
+            "--clip-grad", "3.0", "--amp", "--experiment", "dino16"]
+    _run(dino)
+    ckd = torch.load(tmp_path / "dino16" / "last.pth.tar", weights_only=True)
+    assert ckd["amp_scaler"]["applied_steps"] + ckd["amp_scaler"]["skipped_steps"] == 4 and ckd["amp_scaler"]["applied_steps"] >= 1
+    assert bool(torch.isfinite(ckd["state_dict"]["backbone.blocks.0.attn.qkv.weight"]).all()) and "state_dict_ema" in ckd
+    row = list(csv.DictReader(open(tmp_path / "dino16" / "summary.csv")))[0]
+    assert 5.0 < float(row["train_loss"]) < 8.0
