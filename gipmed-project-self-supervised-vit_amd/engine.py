@@ -783,7 +783,11 @@ class DinoEngine:
         return self.arena.state_dict(self.arena.t if teacher else self.arena.p, "head.")
 
     def grads(self) -> Dict[str, torch.Tensor]:
-        return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
+        """Copies of the parameter gradients of the last forward_backward.  Under float16 loss scaling the arena holds S x gradient:
+        the copies are divided by the scale in force (call before optimizer_step, whose scaler update may change S)."""
+        inv = None if self.scaler is None else 1.0 / self.scaler.state[0]
+        return {n: self.arena.view(self.arena.g, n).detach().clone() if inv is None else self.arena.view(self.arena.g, n).detach() * inv
+                for n in self.arena.specs}
 
     # ---- the step --------------------------------------------------------------------
     def set_drop_path(self, per_img: Optional[torch.Tensor]):
@@ -1069,7 +1073,10 @@ class SupervisedEngine:
         self.grp.set_dropout(p, seed)
 
     def grads(self):
-        return {n: self.arena.view(self.arena.g, n).detach().clone() for n in self.arena.specs}
+        """As DinoEngine.grads: the gradient itself, whatever the loss scale."""
+        inv = None if self.scaler is None else 1.0 / self.scaler.state[0]
+        return {n: self.arena.view(self.arena.g, n).detach().clone() if inv is None else self.arena.view(self.arena.g, n).detach() * inv
+                for n in self.arena.specs}
 
     def forward(self, tiles_u8, ema: bool = False, fill=None):
         """Inference / features: returns (logits f32 [B,C], CLS features bf16 [B,D]); ``ema``: with the EMA weights."""
