@@ -258,6 +258,9 @@ struct BwdCfg {
     static constexpr int NKB = NKT / KT;               // key blocks of 16 KT keys = waves per pair
     static constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
     static constexpr int NW = NKB * PAIRS;             // waves per workgroup
+    // dS^T images.  2 where a (image, head) pair holds its CU alone anyway (N = 197: 142 KB instead of 114): the image alternates per
+    // 64-query step and the step's second barrier goes (72.9 -> 70.4 us per launch; the short classes, several workgroups per CU, keep 1)
+    static constexpr int NDS = NKT == 14 ? 2 : 1;
 };
 template <int NKT, int KT>
 // short sequences run two 4-wave workgroups per CU: the second launch-bounds argument keeps them within 256 registers
@@ -270,7 +273,8 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
     constexpr int QH = NKT >= 8 ? 2 : 1;               // 32-query halves per barrier pair (short sequences keep 1)
     constexpr int DROW = 64 * QH;                      // dS^T image: [key][32 QH q] bf16
     constexpr int DST = NP * DROW;
-    constexpr int PER_PAIR = 3 * IMG + DST + 2 * NP * 4;
+    constexpr int NDS = BwdCfg<NKT, KT>::NDS;          // dS^T images (2: the image alternates per step and the step's second barrier goes)
+    constexpr int PER_PAIR = 3 * IMG + NDS * DST + 2 * NP * 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GV_LDS char* smem = (GV_LDS char*)smem_raw;
     const int lane = threadIdx.x & 63;
@@ -326,8 +330,8 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
     GV_LDS char* Qimg = smem + lp * PER_PAIR;
     GV_LDS char* Kimg = Qimg + IMG;
     GV_LDS char* Dimg = Qimg + 2 * IMG;
-    GV_LDS char* dsT = Qimg + 3 * IMG;
-    GV_LDS float* delta = (GV_LDS float*)(dsT + DST);
+    GV_LDS char* const dsT0 = Qimg + 3 * IMG;
+    GV_LDS float* delta = (GV_LDS float*)(dsT0 + NDS * DST);
     GV_LDS float* lse = delta + NP;
     const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
     const float c = a.scale * 1.4426950408889634f;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
     __syncthreads();
     if (dq_has) {
         GV_LDS char* P0 = smem + dq_pr * PER_PAIR;
-        GV_LDS float* dl = (GV_LDS float*)(P0 + 3 * IMG + DST);
+        GV_LDS float* dl = (GV_LDS float*)(P0 + 3 * IMG + NDS * DST);
         float d = delta_q;
         if constexpr (DELTA_LDS) {
             if (dq_live) {
@@ -381,6 +385,9 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
     // fills both halves of the dS^T image, phase B then has 16 dQ tiles to spread over the waves
     const int nqc2 = (N + 32 * QH - 1) / (32 * QH);
     for (int qc2 = 0; qc2 < nqc2; ++qc2) {
+        // NDS = 2: step i writes image i & 1.  Its readers (phase B of step i) come before phase A of step i + 1 in every wave's
+        // program order, hence before the barrier of step i + 1 -- and image i & 1 is next written in step i + 2, behind that barrier
+        GV_LDS char* const dsT = dsT0 + (NDS == 2 ? (qc2 & 1) * DST : 0);
 #pragma unroll
         for (int half = 0; half < QH; ++half) {
             const int qc = qc2 * QH + half;
@@ -472,7 +479,7 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
                 *(bf16x4*)((bf16*)a.dqkv + ((long)img * N + q) * ld + h * 64 + dt * 16 + 4 * g) =
                     bf16x4{(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
         }
-        __syncthreads();
+        if constexpr (NDS == 1) __syncthreads();
     }
     // ---- dK, dV: lane = key, rows d = 16 dt + 4 g + r
     if (valid) {
@@ -506,8 +513,8 @@ template <int NKT> int launch_fwd(const gv_attention_fwd_args* a, hipStream_t s)
 template <int NKT, int KT> int launch_bwd(const gv_attention_bwd_args* a, hipStream_t s) {
     using B = BwdCfg<NKT, KT>;
     constexpr int PAIRS = B::PAIRS, NW = B::NW, NP = NKT * 16;
-    constexpr int LDS = PAIRS * (3 * NP * 128 + NP * (NKT >= 8 ? 128 : 64) + 2 * NP * 4);
-    static_assert(NW * 64 <= 1024, "workgroup size");
+    constexpr int LDS = PAIRS * (3 * NP * 128 + B::NDS * NP * (NKT >= 8 ? 128 : 64) + 2 * NP * 4);
+    static_assert(NW * 64 <= 1024 && LDS <= 160 * 1024, "workgroup size / LDS");
     auto kern = attn_bwd_kernel<NKT, KT>;
     static GvLdsOptIn opt_in;
     if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, LDS, "gv_attention_bwd")) return rc;
