@@ -41,6 +41,22 @@ def test_act_format_selects_the_library_build():
     assert r.returncode != 0 and "built for 16-bit format 0" in r.stderr
 
 
+def test_loss_scaler_state_interchanges_with_torch_gradscaler():
+    """The checkpoint entry 'amp_scaler' (timm CheckpointSaver(amp_scaler=...), reference train.py:585-602) is torch's
+    GradScaler.state_dict(): LossScaler reads that layout and writes a superset of it."""
+    from gipvit import ops
+    torch_state = torch.amp.GradScaler("cpu", init_scale=4096.0, growth_interval=100).state_dict()
+    assert set(torch_state) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    sc = ops.LossScaler("cpu")
+    assert sc.state.tolist() == [65536.0, 0.0, 0.0, 0.0] and (sc.growth_factor, sc.backoff_factor, sc.growth_interval) == (2.0, 0.5, 2000)
+    sc.load_state_dict(dict(torch_state, _growth_tracker=7))
+    assert sc.state.tolist() == [4096.0, 7.0, 0.0, 0.0] and sc.growth_interval == 100
+    out = sc.state_dict()
+    assert all(out[k] == v for k, v in dict(torch_state, _growth_tracker=7).items()) and out["applied_steps"] == 0
+    back = torch.amp.GradScaler("cpu")
+    back.load_state_dict({k: out[k] for k in torch_state})          # and torch reads ours
+
+
 def test_struct_layout_matches_header():
     """sizeof of every args struct as the C compiler sees it == ctypes' view."""
     from gipvit import _lib
