@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# One HIP runtime per process: torch ships its own libamdhip64.so and the tensors whose pointers this library receives live in ITS
+# context.  Loaded first, this library would pull in /opt/rocm's copy, torch a second one later, and every launch from here would fail
+# with "no ROCm-capable device is detected" -- so torch goes first, whatever the importer's order.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 # The 16-bit operand / activation format is a property of the library BUILD (include/gipvit.h gv_act_format): bfloat16 in
 # libgipvit_hip.so, IEEE half in libgipvit_hip_f16.so (the same sources with -DGV_ACT_F16; --amp --amp-dtype float16).  One
