@@ -174,18 +174,19 @@ def main():
     # BENCH_FORCE_DIST=1: take the RCCL path even at world size 1 (rehearses process-group set-up, the
     # ranged all-reduces and the barrier on a one-GPU box; the all-reduces then run over a single rank)
     force_dist = bool(os.environ.get("BENCH_FORCE_DIST")) and "RANK" in os.environ
-    rccl_ranks = 1
+    rccl_ranks, dist_backend, comm = 1, None, {"comm_cus": 0, "cu_budget": 256}
     if world > 1 or force_dist:
         import torch.distributed as dist
-        backend = os.environ.get("BENCH_DIST_BACKEND", "gloo" if share else "nccl")      # "nccl" IS RCCL on ROCm
+        from gipvit.dist import RcclReducer, comm_setup, quiet_init_process_group
+        backend = dist_backend = os.environ.get("BENCH_DIST_BACKEND", "gloo" if share else "nccl")      # "nccl" IS RCCL on ROCm
+        comm = comm_setup(world, backend)      # CUs left to RCCL's channels + the matching launch budget (before the library loads)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            quiet_init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(backend)
-        from gipvit.dist import RcclReducer
+            quiet_init_process_group(backend)
         reducer = RcclReducer()
-        reducer.always = force_dist      # rehearsal: issue the per-block ranges at world size 1 too
-        rccl_ranks = dist.get_world_size()
+        reducer.always = force_dist      # rehearsal: issue the coalesced ranges at world size 1 too
+        rccl_ranks = dist.get_world_size() if backend == "nccl" else 0       # ranks RCCL carries (0: another transport, see dist_backend)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -258,20 +259,31 @@ def main():
     # steps contain the data-parallel all-reduces), reported from rank 0
     roof = roofline.dominant_kernel_roofline(lambda: on_main(lambda: eng.step(tiles)), steps=3, vit=eng.vit)
 
+    # FLOPs actually executed per tile: BASELINE.md's count prices every token of every block (what the reference's module + autograd
+    # compute); with the CLS-only last block (engine.VitRunner.cls_last) the projection + MLP of that block skip the non-CLS rows --
+    # per such row 18 D^2 forward, and for the student 18 D^2 (dX) + 18 D^2 (dW) more in backward.
+    gflop_ref = GFLOP_PER_TILE.get((args.arch, args.config))
+    cls_only = bool(eng.vit._cls_tail(eng.g_stu))
+    gflop_exec = gflop_ref
+    if gflop_ref is not None and cls_only:
+        rows_g, rows_l = 2 * (224 // 16) ** 2, n_local * (96 // 16) ** 2
+        gflop_exec = gflop_ref - (54 * (rows_g + rows_l) + 18 * rows_g) * eng.D ** 2 / 1e9
     if rank == 0:
         tiles_s = args.batch * args.micro * world * args.steps / dt
         out = {
             "metric": "tiles/sec/GPU ViT-S/16 DINO (2g+8l crops, 256px) at 1/2/4/8 MI355X",
             "value": round(tiles_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "f16": "f16", "bf16": "bf16"}[args.precision], "data": "synthetic", "rccl_ranks": rccl_ranks,
+            "dtype": {"fp32": "f32", "f16": "f16", "bf16": "bf16"}[args.precision], "data": "synthetic", "rccl_ranks": rccl_ranks, "dist_backend": dist_backend,
             "config": {"workload": f"{args.arch}/16 DINO 2x224+{n_local}x96 crops of 256px NHWC u8 tiles, K=65536 ({args.config})",
                        "tiles_per_gpu": args.batch * args.micro, "micro_batches": args.micro, "global_tiles": args.batch * args.micro * world, "parallelism": f"dp{world}",
-                       "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops), "view_augment": bool(args.view_augment and args.random_crops)},
+                       "comm_cus": comm["comm_cus"], "cu_budget": comm["cu_budget"], "side_stream": eng.vit.side is not None, "main_stream_high_priority": main_stream is not None, "random_crops": bool(args.random_crops), "view_augment": bool(args.view_augment and args.random_crops)},
             "tiles_per_s_per_gpu": round(tiles_s / world, 2),
-            "mfma_frac_whole_step": round(tiles_s / world * GFLOP_PER_TILE[(args.arch, args.config)] / 1e3
+            "cls_only_last_block": cls_only,
+            "gflop_per_tile": None if gflop_ref is None else {"every_token_of_every_block": gflop_ref, "executed": round(gflop_exec, 2)},
+            "mfma_frac_whole_step": round(tiles_s / world * gflop_exec / 1e3
                                           / (MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_BF16_PEAK_TFLOPS), 4)
-            if (args.arch, args.config) in GFLOP_PER_TILE else None,
+            if gflop_ref is not None else None,
             "final_loss": round(loss, 4),
         }
         out["roofline"] = roof

@@ -170,7 +170,8 @@ int dw8_pick_slices(int tiles, int ktiles, long mn_floats, long workspace_bytes)
     int best = 1; long best_cost = -1;
     for (int S = 1; S <= 64; ++S) {
         if (S > 1 && (ktiles / S < 4 || (long)S * mn_floats * 4 > workspace_bytes)) break;
-        const long cost = (long)((tiles * S + 255) / 256) * ((ktiles + S - 1) / S);
+        const int cus = gv_cu_budget();
+        const long cost = (long)((tiles * S + cus - 1) / cus) * ((ktiles + S - 1) / S);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = S; }
     }
     return best;

@@ -58,6 +58,16 @@ static inline int gv_lds_opt_in(GvLdsOptIn& st, const void* kern, int bytes, con
     return GV_OK;
 }
 
+// Compute units the one-workgroup-per-CU launches (full-row / wide products, grouped weight gradients) are sized for: 256, or
+// 256 - C when the process leaves C CUs to RCCL's channel workgroups (GIPVIT_CU_BUDGET, set by the drivers before the library is
+// loaded when the data-parallel world has more than one rank -- every such launch holds a CU's whole register file and LDS, so a
+// communication workgroup cannot co-reside: without the budget it would push a 251-workgroup launch into a second round).
+#include <stdlib.h>
+static inline int gv_cu_budget() {
+    static const int b = [] { const char* e = getenv("GIPVIT_CU_BUDGET"); const int v = e ? atoi(e) : 256; return (v >= 64 && v <= 256) ? v : 256; }();
+    return b;
+}
+
 // ---- wave-level reductions (64-lane wavefront) ------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

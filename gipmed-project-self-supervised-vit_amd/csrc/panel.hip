@@ -724,11 +724,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 
 // rows per workgroup for M rows: the smallest supported FM that covers M in as few full rounds of 256 workgroups as possible
 constexpr int FM_SET8[] = {4, 7, 9, 11, 12};
-#ifdef GV_LAB_CU_BUDGET      // lab: size the launches for a share of the chip (two half-batch steps side by side, tools/concurrent_micro.py)
-int cu_budget() { static const int b = [] { const char* e = getenv("GIPVIT_CU_BUDGET"); return e ? atoi(e) : 256; }(); return b; }
-#else
-constexpr int cu_budget() { return 256; }
-#endif
+int cu_budget() { return gv_cu_budget(); }       // 256, or 256 - C under a data-parallel run that leaves C CUs to RCCL (gv_common.h)
 int pick_fm(int M) {
     const int m16 = (M + 15) / 16;
     const int rounds = (m16 + cu_budget() * 12 - 1) / (cu_budget() * 12);
@@ -745,9 +741,13 @@ int wide_grid(int M, int BM, int ncb) {
     const int P = (M + BM - 1) / BM, groups = (P + ncb - 1) / ncb;
     return 8 * ncb * ((groups + 7) / 8);
 }
-// ... and the smallest supported FM whose launch is one round of workgroups (<= 256); 12 (several rounds) for larger M
+// ... and the smallest supported FM whose WORKING workgroups (ncb per group of panels; the grid's padding to 8 ncb exits at once)
+// fit one round of the CU budget; 12 (several rounds) for larger M
 int pick_fm_wide(int M, int ncb) {
-    for (int fm : FM_SET8) if (wide_grid(M, 16 * fm, ncb) <= cu_budget()) return fm;
+    for (int fm : FM_SET8) {
+        const int P = (M + 16 * fm - 1) / (16 * fm), groups = (P + ncb - 1) / ncb;
+        if (groups * ncb <= cu_budget() && wide_grid(M, 16 * fm, ncb) <= 256) return fm;
+    }
     return 12;
 }
 
@@ -809,6 +809,9 @@ int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
 // the hot path's epilogues, on the full-row kernel -- row panels sized for ONE round of workgroups, 768-B row segments out.
 // Returns -1 when the call is not one of these (the caller then runs the 128x128-tile kernel).
 int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
+#ifdef GV_LAB_WIDE2      // lab build with tools/lab/panel2.hip linked in: the two-context form of these products (measured, slower: LAB_NOTES.md)
+    { extern int gv_panel_wide2(const gv_linear_args*, hipStream_t); const int rc2 = gv_panel_wide2(a, s); if (rc2 != -1) return rc2; }
+#endif
     if (a->trans_a || a->N % PN != 0 || a->K % 128 != 0 || a->M < 2048 || a->ldc % 2 != 0) return -1;
     if (a->alpha != 0.f && a->alpha != 1.f) return -1;
     const bool plan = s == (hipStream_t)(intptr_t)-1;       // gv_workspace_bytes: "would this call run here?" (these kernels take no scratch)

@@ -14,6 +14,46 @@ import torch
 import torch.distributed as dist
 
 
+def comm_setup(world: int, backend: str = "nccl") -> dict:
+    """Make room on the chip for RCCL before the process group AND the kernel library exist.  Every heavy launch of this build is
+    sized to one workgroup per CU holding the CU's whole register file and LDS, so RCCL's channel workgroups cannot co-reside
+    with them: with more than one rank, C = GIPVIT_COMM_CUS (default 8) compute units are left to communication -- the library
+    sizes its launches for 256 - C (GIPVIT_CU_BUDGET, read once when it is loaded) and RCCL is capped to C channels
+    (NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS; values already in the environment win).  Returns what was decided, for the
+    log / JSON line.  No-op at world size 1 and for the gloo rehearsal transport."""
+    import os
+    import sys
+    info = {"comm_cus": 0, "cu_budget": int(os.environ.get("GIPVIT_CU_BUDGET", "256"))}
+    if world <= 1 or backend != "nccl":
+        return info
+    if "gipvit._lib" in sys.modules and "GIPVIT_CU_BUDGET" not in os.environ:
+        raise RuntimeError("comm_setup() must run before the kernel library is loaded (the CU budget is read once at load)")
+    c = int(os.environ.get("GIPVIT_COMM_CUS", "8"))
+    if c > 0:
+        os.environ.setdefault("GIPVIT_CU_BUDGET", str(256 - c))
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(c))
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(c, 4)))
+    info.update(comm_cus=c, cu_budget=int(os.environ["GIPVIT_CU_BUDGET"]) if c > 0 else 256,
+                nccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS"))
+    return info
+
+
+def quiet_init_process_group(backend: str, **kw):
+    """init_process_group with file descriptor 1 pointed at stderr meanwhile: gloo's transport prints "[Gloo] Rank 0 is connected ..."
+    on stdout, where bench.py owes the driver exactly one JSON line."""
+    import os
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        dist.init_process_group(backend, **kw)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class RcclReducer:
     def __init__(self, group=None):
         self.group = group
@@ -32,6 +72,37 @@ class RcclReducer:
         for w in self._pending:
             w.wait()            # current stream waits for the communication stream
         self._pending.clear()
+
+
+def reduction_plan(head_span, block_spans, n_total: int, bucket_bytes: int = 25 << 20, elt: int = 4):
+    """Contiguous arena ranges of one step's gradient all-reduce, in the order they become final in backward.
+
+    ``head_span``: (lo, hi) of the head's weight-decayed matrices (final when the head backward ends; None when there is no
+    head), ``block_spans``: {block index: (lo, hi)} of every transformer block's matrices -- the arena lays them out in
+    backward-completion order (head, block depth-1 .. 0, patch embed, then the no-decay tensors), ``n_total``: arena length.
+    Returns ``[(trigger, lo, hi)]``: trigger "head" (released when the head backward ends), a block index (released when that
+    block's backward ends) or "end" (released when backward ends).  Blocks are coalesced until a range holds at least
+    ``bucket_bytes`` (the reference's DDP reduces 25-MB buckets, train.py:634: a 7-MB ViT-S block alone is a latency-bound
+    message).  The LAST range is block 0 together with everything behind it in the arena -- patch embed and the no-decay
+    tensors, final only when backward ends -- so one message, not a block range plus a small tail, is issued there; to keep
+    that un-overlapped message short, the bucket in front of it is closed at block 1 whatever its size.
+    The ranges tile [0, n_total) exactly once, in release order."""
+    plan, lo = [], 0
+    if head_span is not None:
+        plan.append(("head", 0, head_span[1]))
+        lo = head_span[1]
+    order = sorted(block_spans, reverse=True)
+    for i in order:
+        b_lo, b_hi = block_spans[i]
+        assert b_lo >= lo, "block spans must follow the arena's backward-completion order"
+        if i == order[-1]:
+            break
+        if (b_hi - lo) * elt >= bucket_bytes or (len(order) > 1 and i == order[-2]):
+            plan.append((i, lo, b_hi))
+            lo = b_hi
+    if lo < n_total:
+        plan.append(("end", lo, n_total))
+    return plan
 
 
 def shard_range(n_items: int, rank: int, world: int):

@@ -243,6 +243,9 @@ class VitGroup:
             self.dh_b, self.dqkv_b = e((T, 4 * D), act), e((T, 3 * D), act)
 
         self.depth, self.device = depth, device
+        # CLS-only last block (VitRunner.cls_last): buffers over the n_img CLS rows, allocated on first use (alloc_cls)
+        self.c_o = None
+        self.D_ = D
         self.dropout, self.tmp = None, None   # --drop: (p, step seed) and the f32 branch-output buffer of the unfused residual adds (set_dropout)
         self.rs = None            # stochastic depth: f32 [depth, 2, T] row factors of the attention / MLP branch (set_drop)
         self.drop_img = None      # ... and the per-image factors they were expanded from
@@ -280,6 +283,30 @@ class VitGroup:
         if self.tmp is None:
             self.tmp = _empty(tuple(self.x[0].shape), f32, self.device)
 
+    def alloc_cls(self):
+        """Buffers of the last block's CLS-only tail: n_img rows instead of T (one per crop image, images in segment order)."""
+        if self.c_o is not None:
+            return
+        n, D, act = self.n_img, self.D_, self.act
+        e = lambda shape, dt: _empty(shape, dt, self.device)
+        self.c_o, self.c_xn2 = e((n, D), act), e((n, D), act)
+        self.c_xa, self.c_xb, self.c_xc = e((n, D), f32), e((n, D), f32), e((n, D), f32)
+        self.c_h, self.c_hp = e((n, 4 * D), act), e((n, 4 * D), act)
+        self.c_stats = [e((n,), f32), e((n,), f32)]                      # mean2, rstd2
+        if self.save:
+            self.c_g, self.c_gb, self.c_gb_att = e((n, D), f32), e((n, D), act), e((n, D), act)
+            self.c_dh, self.c_dxn, self.c_do = e((n, 4 * D), act), e((n, D), act), e((n, D), act)
+
+    def gather_cls(self, src: torch.Tensor, dst: torch.Tensor):
+        """dst[image] = src[the image's CLS row] (strided copies, one per segment)."""
+        for sg in self.segs:
+            dst[sg.img0:sg.img0 + sg.n_img].copy_(sg.rows(src).view(sg.n_img, sg.N, -1)[:, 0])
+
+    def scatter_cls(self, src: torch.Tensor, dst: torch.Tensor):
+        """dst[the image's CLS row] = src[image]; the other rows of dst are left as they are."""
+        for sg in self.segs:
+            sg.rows(dst).view(sg.n_img, sg.N, -1)[:, 0].copy_(src[sg.img0:sg.img0 + sg.n_img])
+
     def xbuf(self, j):
         return self.x[j] if self.save else self.x[j % 3]
 
@@ -300,6 +327,11 @@ class VitRunner:
         # traffic and four times longer k-loops than four launches (ViT-S: 165 us per block at 950 TFLOP/s against
         # 4 x (51 + 7) us).  GIPVIT_GROUP_DW=0 keeps one launch per product for A/B runs.
         self.group_dw = not fp32 and os.environ.get("GIPVIT_GROUP_DW", "1") != "0"
+        # Only the CLS row of the last block's output feeds the head (vit.pyc@L248-253: forward returns x[:, 0]), so that block's
+        # attention projection, MLP and residual adds for the other tokens -- and their whole backward except the K / V path --
+        # are dead values: the last block runs them on the n_img CLS rows only (same loss and gradients; ~5.7 % fewer FLOPs of a
+        # ViT-S DINO step).  GIPVIT_CLS_ONLY_LAST=0 computes every token of every block, as the reference's module + autograd do.
+        self.cls_last = os.environ.get("GIPVIT_CLS_ONLY_LAST", "1") != "0"
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
         self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
@@ -358,6 +390,9 @@ class VitRunner:
             else:
                 for sg in G.segs:
                     ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s])
+            if self._cls_tail(G) and i == self.depth - 1:
+                self._last_block_tail_fwd(W, G, i, xa, fused)
+                break
             if fused:
                 ops.linear_ln_fwd(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, bias=W.f(b + "attn.proj.bias"), resid=xa,
                                   gamma=W.f(b + "norm2.weight"), beta=W.f(b + "norm2.bias"), y=G.xn2[s], mean=st[2], rstd=st[3], row_scale=rs_a)
@@ -390,8 +425,40 @@ class VitRunner:
         xl = G.xbuf(2 * self.depth)
         for sg in G.segs:
             r0 = row_off + sg.img0
-            ops.layernorm_fwd(sg.rows(xl), W.f("norm.weight"), W.f("norm.bias"), sg.n_img, D, x_stride=sg.N * D,
-                              y=feats[r0:r0 + sg.n_img], mean=sg.fstats[0], rstd=sg.fstats[1])
+            if self._cls_tail(G):         # the last block left its output for the CLS rows only, contiguous
+                ops.layernorm_fwd(G.c_xc[sg.img0:sg.img0 + sg.n_img], W.f("norm.weight"), W.f("norm.bias"), sg.n_img, D,
+                                  y=feats[r0:r0 + sg.n_img], mean=sg.fstats[0], rstd=sg.fstats[1])
+            else:
+                ops.layernorm_fwd(sg.rows(xl), W.f("norm.weight"), W.f("norm.bias"), sg.n_img, D, x_stride=sg.N * D,
+                                  y=feats[r0:r0 + sg.n_img], mean=sg.fstats[0], rstd=sg.fstats[1])
+
+    def _cls_tail(self, G: VitGroup) -> bool:
+        """Does this group run the last block's projection / MLP on the CLS rows only?  (Training groups: on the grouped
+        weight-gradient path and without --drop, whose backward this build restates for that case.)"""
+        return self.cls_last and G.dropout is None and (not G.save or self.group_dw)
+
+    def _last_block_tail_fwd(self, W: Weights, G: VitGroup, i: int, xa: torch.Tensor, fused: bool):
+        """x + proj(attention) -> norm2 -> MLP -> residual of block i for the CLS rows only (vit.pyc@L146-152 on the rows that
+        VisionTransformer.forward returns, L248-253): n_img rows through the same kernels the full blocks use."""
+        G.alloc_cls()
+        D, n, s, E, b = self.D, G.n_img, G.slot(i), L, f"blocks.{i}."
+        rs_a, rs_m = (G.drop_img[i, 0], G.drop_img[i, 1]) if G.rs is not None else (None, None)       # per image = per CLS row
+        G.gather_cls(G.o[s], G.c_o)
+        G.gather_cls(xa, G.c_xa)
+        if fused:
+            ops.linear_ln_fwd(G.c_o, W.w(b + "attn.proj.weight"), G.c_xb, n, D, bias=W.f(b + "attn.proj.bias"), resid=G.c_xa,
+                              gamma=W.f(b + "norm2.weight"), beta=W.f(b + "norm2.bias"), y=G.c_xn2, mean=G.c_stats[0], rstd=G.c_stats[1], row_scale=rs_a)
+        else:
+            ops.linear(G.c_o, W.w(b + "attn.proj.weight"), G.c_xb, n, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
+                       bias=W.f(b + "attn.proj.bias"), resid=G.c_xa, row_scale=rs_a)
+            ops.layernorm_fwd(G.c_xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), n, D, y=G.c_xn2, mean=G.c_stats[0], rstd=G.c_stats[1])
+        ops.linear(G.c_xn2, W.w(b + "mlp.fc1.weight"), G.c_h, n, 4 * D, D, epilogue=E.EPI_BIAS | E.EPI_GELU | (E.EPI_SAVE_PRE if G.save else 0),
+                   bias=W.f(b + "mlp.fc1.bias"), aux_out=G.c_hp if G.save else None)
+        if fused:
+            ops.linear_ln_fwd(G.c_h, W.w(b + "mlp.fc2.weight"), G.c_xc, n, 4 * D, bias=W.f(b + "mlp.fc2.bias"), resid=G.c_xb, row_scale=rs_m)
+        else:
+            ops.linear(G.c_h, W.w(b + "mlp.fc2.weight"), G.c_xc, n, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
+                       bias=W.f(b + "mlp.fc2.bias"), resid=G.c_xb, row_scale=rs_m)
 
     def _fin3(self, dgamma, dbeta, dbias):
         ops.ln_finalize(self.partials, L.LN_PARTIAL_BLOCKS, self.D, dgamma, dbeta, dbias)
@@ -415,15 +482,23 @@ class VitRunner:
             ops.colsum(gb, T, D, self.cs_ws, bias_grad, accumulate=True)
         sets = ((G.gb, G.gb2, G.dh, G.dqkv), (G.gb3, G.gb4, G.dh_b, G.dqkv_b))      # per block parity: dY of the MLP / attention half, dh, dqkv
         gb_first = sets[(self.depth - 1) & 1][0] if grouped else G.gb
-        G.g.zero_(); gb_first.zero_()
+        cls_tail = self._cls_tail(G)          # the last block ran its projection / MLP on the CLS rows only (forward): so does its backward
+        G.g.zero_()
+        if not cls_tail:
+            gb_first.zero_()
         xl = G.x[2 * self.depth]
         # stochastic depth: the bf16 gradient handed to a branch carries that branch's row factor (rs[i, 0] attention, rs[i, 1] MLP)
         rs = G.rs
         for sg in G.segs:
             # (the final norm touches the CLS rows only, one per image: the per-image factors are its row factors)
-            ops.layernorm_bwd(dfeat[sg.img0:sg.img0 + sg.n_img], sg.rows(xl), sg.fstats[0], sg.fstats[1], W.f("norm.weight"), sg.rows(G.g),
-                              sg.rows(gb_first), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True,
-                              gb_scale=None if rs is None else G.drop_img[self.depth - 1, 1, sg.img0:sg.img0 + sg.n_img])
+            im = slice(sg.img0, sg.img0 + sg.n_img)
+            if cls_tail:
+                ops.layernorm_bwd(dfeat[im], G.c_xc[im], sg.fstats[0], sg.fstats[1], W.f("norm.weight"), G.c_g[im], G.c_gb[im], self.partials,
+                                  sg.n_img, D, g_init=True, gb_scale=None if rs is None else G.drop_img[self.depth - 1, 1, im])
+            else:
+                ops.layernorm_bwd(dfeat[im], sg.rows(xl), sg.fstats[0], sg.fstats[1], W.f("norm.weight"), sg.rows(G.g),
+                                  sg.rows(gb_first), self.partials, sg.n_img, D, x_stride=sg.N * D, g_stride=sg.N * D, gb_stride=sg.N * D, g_init=True,
+                                  gb_scale=None if rs is None else G.drop_img[self.depth - 1, 1, im])
             self._fin3(W.g("norm.weight"), W.g("norm.bias"), None if dp else W.g(f"blocks.{self.depth - 1}.mlp.fc2.bias"))
         # The weight-gradient GEMMs are off the critical path (nothing in backward consumes dW):
         # they run on a side stream beside the dX chain, so their tiles fill the tail of every
@@ -461,18 +536,20 @@ class VitRunner:
         # partials buffers rotate; one is rewritten only after the finalize that read it (three calls ago) has run.
         ring, fin_ev, ring_i, last_side = self.partials_ring, [None, None, None], [0], [None]
 
-        def ln_bwd(dy, x, mean, rstd, gamma, gb, d0, d1, d2, dx_of=None, gb_scale=None):
+        def ln_bwd(dy, x, mean, rstd, gamma, gb, d0, d1, d2, dx_of=None, gb_scale=None, rows=None, g=None):
             """LayerNorm backward into the residual gradient.  ``dx_of = (dY, W, K)``: the dX product that produces ``dy``
-            runs fused with it (gv_linear_ln_bwd) and ``dy`` never exists in HBM."""
+            runs fused with it (gv_linear_ln_bwd) and ``dy`` never exists in HBM.  ``rows`` / ``g``: a row count and residual
+            gradient other than the group's T rows / G.g (the last block's CLS-only tail)."""
             k = ring_i[0]
             ring_i[0] = (k + 1) % 3
             join(fin_ev[k])
+            M_, g_ = (T if rows is None else rows), (G.g if g is None else g)
             if dx_of is not None and fused_b:
-                nblk = ops.linear_ln_bwd(dx_of[0], dx_of[1], x, mean, rstd, gamma, G.g, gb, ring[k], T, dx_of[2], gb_scale=gb_scale)
+                nblk = ops.linear_ln_bwd(dx_of[0], dx_of[1], x, mean, rstd, gamma, g_, gb, ring[k], M_, dx_of[2], gb_scale=gb_scale)
             else:
                 if dx_of is not None:
-                    ops.linear(dx_of[0], dx_of[1], dy, T, D, dx_of[2], trans_b=True)
-                ops.layernorm_bwd(dy, x, mean, rstd, gamma, G.g, gb, ring[k], T, D, gb_scale=gb_scale)
+                    ops.linear(dx_of[0], dx_of[1], dy, M_, D, dx_of[2], trans_b=True)
+                ops.layernorm_bwd(dy, x, mean, rstd, gamma, g_, gb, ring[k], M_, D, gb_scale=gb_scale)
                 nblk = L.LN_PARTIAL_BLOCKS
             if side is None:
                 ops.ln_finalize(ring[k], nblk, D, d0, d1, d2)
@@ -494,6 +571,17 @@ class VitRunner:
                 e1 = new_event(); e1.record(side)
             return e1
 
+        def on_side(fn):
+            """``fn()`` on the side stream once main's work so far is done; returns the event that marks its end."""
+            if side is None:
+                fn()
+                return None
+            e0 = new_event(); e0.record(main); side.wait_event(e0)
+            with torch.cuda.stream(side):
+                fn()
+                e1 = new_event(); e1.record(side)
+            return e1
+
         def report(i):
             if on_block_done is not None:
                 # the block's weight gradients are produced by the side stream: report the block from
@@ -511,6 +599,35 @@ class VitRunner:
             gb_mlp, gb_att, dh, dqkv = sets[par]
             gb_next = sets[par ^ 1][0]                    # dY of block i - 1's MLP half
             join(done_grp[par])                           # block i + 2's group read this parity's buffers
+            if cls_tail and i == self.depth - 1:
+                # ---- last block, CLS rows only (forward: _last_block_tail_fwd): MLP and projection backward over n_img rows; the
+                # attention backward and the qkv product's dX + norm1 backward then run over all tokens as in every block, with
+                # dO and the residual gradient zero outside the CLS rows (only K and V of the other tokens reached the output)
+                n = G.n_img
+                ops.linear(G.c_gb, W.w(b + "mlp.fc2.weight"), G.c_dh, n, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.c_hp)
+                ln_bwd(G.c_dxn, G.c_xb, G.c_stats[0], G.c_stats[1], W.f(b + "norm2.weight"), G.c_gb_att,
+                       W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"),
+                       dx_of=(G.c_dh, W.w(b + "mlp.fc1.weight"), 4 * D), gb_scale=None if rs is None else G.drop_img[i, 0], rows=n, g=G.c_g)
+                ops.linear(G.c_gb_att, W.w(b + "attn.proj.weight"), G.c_do, n, D, D, trans_b=True)
+                G.do.zero_()
+                G.scatter_cls(G.c_do, G.do)
+                G.scatter_cls(G.c_g, G.g)                 # (G.g was zeroed above)
+                for sg in G.segs:
+                    ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(dqkv))
+                ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
+                       W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
+                       dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])
+
+                def last_block_dw():
+                    # three weight gradients reduce over the n CLS rows, the qkv one over all tokens
+                    ops.linear(G.c_gb, G.c_h, W.g(b + "mlp.fc2.weight"), D, 4 * D, n, trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
+                    ops.linear(G.c_dh, G.c_xn2, W.g(b + "mlp.fc1.weight"), 4 * D, D, n, trans_a=True, trans_b=True, epilogue=ACC,
+                               colsum_a=W.g(b + "mlp.fc1.bias"), workspace=self.ws)
+                    ops.linear(G.c_gb_att, G.c_o, W.g(b + "attn.proj.weight"), D, D, n, trans_a=True, trans_b=True, epilogue=ACC, workspace=self.ws)
+                    ops.linear_dw_group([(dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), W.g(b + "attn.qkv.bias"))], T, self.ws)
+                done_grp[par] = on_side(last_block_dw)
+                report(i)
+                continue
             if dp:
                 drop_branch_grad(gb_mlp, i, 3, W.g(b + "mlp.fc2.bias"))
             ops.linear(gb_mlp, W.w(b + "mlp.fc2.weight"), dh, T, 4 * D, D, trans_b=True, epilogue=E.EPI_DGELU, aux_in=G.hp[i])
@@ -737,6 +854,7 @@ class DinoEngine:
         self.t = 0
         self.reducer = reducer if reducer is not None else NoReducer()
         self._n_micro = 1
+        self._plan = None             # gradient all-reduce ranges (dist.reduction_plan), built on first use
         # the teacher's forward runs on the side stream beside the student's; GIPVIT_TEACHER_SIDE=0 queues it in front instead (A/B runs)
         self._teacher_on_side = os.environ.get("GIPVIT_TEACHER_SIDE", "1") != "0"
         if torch.device(device).type == "cuda":
@@ -889,32 +1007,35 @@ class DinoEngine:
         if not last:        # more micro-batches follow: gradients keep accumulating locally
             self.vit.backward(self.sW, self.g_stu, self.hb_s.dfeats)
             return
-        # head gradients are final: start their reduction while the backbone runs backward
-        head_names = [n for n in a.order if n.startswith("head.") and a.off[n] < a.n_decay]
-        if head_names:
-            lo = min(a.off[n] for n in head_names)
-            hi = max(a.off[n] + _round_up(math.prod(a.specs[n]), PAD) for n in head_names)
-            if side is not None:          # the head's weight gradients were queued on the side stream
-                with torch.cuda.stream(side):
-                    self.reducer.reduce_range(a.g, lo, hi)
-            else:
-                self.reducer.reduce_range(a.g, lo, hi)
-            self._reduced_hi = hi
+        # The gradient all-reduce goes out as a few contiguous arena ranges, each as soon as it is final (dist.reduction_plan):
+        # the head's matrices when the head backward ends, then coalesced block ranges of >= 25 MB from the side stream (the
+        # block's weight gradients are produced there), then block 0 + patch embed + the no-decay tail as ONE message when
+        # backward ends -- RCCL's stream runs beside the remaining backward (reference: NativeDDP's buckets, train.py:634, 1071)
+        plan = self._reduction_plan()
+        active = self.reducer.world > 1 or getattr(self.reducer, "always", False)
+
+        def release(trigger):
+            if active:
+                for trg, lo, hi in plan:
+                    if trg == trigger:
+                        self.reducer.reduce_range(a.g, lo, hi)
+        if side is not None:              # the head's weight gradients were queued on the side stream
+            with torch.cuda.stream(side):
+                release("head")
         else:
-            self._reduced_hi = 0
-        # every block's weight gradients are final when its backward ends -> reduce that block's
-        # contiguous arena range right away (RCCL's stream runs beside the remaining backward)
-        state = {"hi": self._reduced_hi}
-
-        def block_done(i):
-            lo, hi = self._block_range[i]
-            if self.reducer.world > 1 or getattr(self.reducer, "always", False):
-                self.reducer.reduce_range(a.g, min(lo, state["hi"]), hi)
-                state["hi"] = hi
-
-        self.vit.backward(self.sW, self.g_stu, self.hb_s.dfeats, on_block_done=block_done)
-        self.reducer.reduce_range(a.g, state["hi"], a.n)          # patch embed + the no-decay segment
+            release("head")
+        self.vit.backward(self.sW, self.g_stu, self.hb_s.dfeats, on_block_done=release)
+        release("end")
         self.reducer.finish()
+
+    def _reduction_plan(self):
+        if self._plan is None:
+            from .dist import reduction_plan
+            a = self.arena
+            head_names = [n for n in a.order if n.startswith("head.") and a.off[n] < a.n_decay]
+            head_span = (min(a.off[n] for n in head_names), max(a.span(n)[1] for n in head_names)) if head_names else None
+            self._plan = reduction_plan(head_span, self._block_range, a.n, bucket_bytes=int(os.environ.get("GIPVIT_BUCKET_MB", "25")) << 20)
+        return self._plan
 
     def optimizer_step(self):
         a = self.arena

@@ -207,6 +207,44 @@ def test_reducer_world_size_2_gloo():
         assert shard == (32 * rank, 32 * rank + 32)
 
 
+def test_reduction_plan_tiles_the_arena_in_backward_order():
+    """The gradient all-reduce plan of a data-parallel step (dist.reduction_plan over the real ViT-S + DINOHead arena layout):
+    ranges cover [0, n) exactly once, in the order backward completes them; block ranges are coalesced to >= 25 MB (the
+    reference's DDP bucket, train.py:634), and the last message is block 0 + patch embed + the no-decay tail, released at the end."""
+    from collections import OrderedDict
+    import math
+    from gipvit import engine as E
+    from gipvit.dist import reduction_plan
+    specs = OrderedDict(("backbone." + k, v) for k, v in E.vit_param_specs("vit_small", 224, 0).items())
+    specs.update(("head." + k, v) for k, v in E.dino_head_specs(384, 65536).items())
+    a = E.Arena(specs, "meta", teacher=True)
+    blocks = {}
+    for i in range(12):
+        names = [n for n in a.order if n.startswith(f"backbone.blocks.{i}.") and a.off[n] < a.n_decay]
+        blocks[i] = (min(a.off[n] for n in names), max(a.span(n)[1] for n in names))
+    head = [n for n in a.order if n.startswith("head.") and a.off[n] < a.n_decay]
+    head_span = (min(a.off[n] for n in head), max(a.span(n)[1] for n in head))
+    plan = reduction_plan(head_span, blocks, a.n)
+    assert plan[0] == ("head", 0, head_span[1]) and plan[-1][0] == "end" and plan[-1][2] == a.n
+    pos = 0
+    for trg, lo, hi in plan:                                   # exact tiling, ascending = backward-completion order of the arena
+        assert lo == pos and hi > lo
+        pos = hi
+    assert pos == a.n
+    triggers = [t for t, _, _ in plan]
+    assert triggers == ["head", 8, 4, 1, "end"]                # 4 + 4 + 3 blocks, then block 0 with everything behind it
+    for trg, lo, hi in plan[1:-2]:
+        assert (hi - lo) * 4 >= 25 << 20                       # full buckets (the one in front of the last message may be shorter)
+    for trg, lo, hi in plan[1:-1]:                             # a range released by block i holds only blocks >= i
+        assert lo >= blocks[11][0] and hi == blocks[trg][1] and all(j >= trg for j in range(12) if lo <= blocks[j][0] and blocks[j][1] <= hi)
+    last_lo = plan[-1][1]
+    assert last_lo == blocks[0][0] and a.off["backbone.patch_embed.proj.weight"] >= last_lo and a.n_decay < a.n
+    assert (a.n - last_lo) * 4 < 12 << 20                      # the un-overlapped message stays short (ViT-S: 7.8 MB)
+    # a one-block model and a headless one still tile
+    assert reduction_plan(None, {0: (0, 100)}, 130) == [("end", 0, 130)]
+    assert reduction_plan((0, 50), {1: (50, 80), 0: (80, 100)}, 130, bucket_bytes=1 << 30) == [("head", 0, 50), (1, 50, 80), ("end", 80, 130)]
+
+
 def test_train_cli_keeps_reference_surface(tmp_path):
     """Every flag of the reference trainer parses (documented command lines of
     train_instruct.txt:16-34 included), YAML -c defaults work, and without a GPU the driver

@@ -114,6 +114,18 @@ def test_tiles_dataset_through_pinned_prefetcher(dev, tmp_path):
     assert rc == 0
     r = list(csv.DictReader(open(tmp_path / "aug" / "summary.csv")))
     assert len(r) == 1 and 0.3 < float(r[0]["train_loss"]) < 1.2
+    # --test_fold -1 is the reference's "no validation" setting (train.py:367; datasets.py:284-287 give folds = []): the driver
+    # trains on every fold (no 'test' / 'val' rows here) and skips validate() instead of failing on the empty evaluation selection
+    rc = train.main(["--model", "vit_tiny_patch16_224", "--dataset", f"tiles:{root}", "--num-classes", "2", "--img-size", "64", "--tile-size", "64",
+                     "-b", "4", "--epochs", "1", "--opt", "adamw", "--lr", "1e-4", "--warmup-epochs", "0", "--output", str(tmp_path), "--experiment", "nofold",
+                     "--n_patches_train", "4", "--test_fold", "-1", "--transform_type", "none", "--log-interval", "1"])
+    assert rc == 0
+    r = list(csv.DictReader(open(tmp_path / "nofold" / "summary.csv")))
+    assert len(r) == 1 and np.isfinite(float(r[0]["train_loss"])) and not r[0].get("eval_loss")
+    # ... but a run that asks for evaluation slides of a fold nobody is in still fails loudly
+    with pytest.raises(ValueError, match="no evaluation slides"):
+        train.main(["--model", "vit_tiny_patch16_224", "--dataset", f"tiles:{root}", "--num-classes", "2", "--img-size", "64", "--tile-size", "64",
+                    "-b", "4", "--epochs", "1", "--opt", "adamw", "--output", str(tmp_path), "--experiment", "badfold", "--test_fold", "7"])
 
 
 def test_train_dino_checkpoint_and_resume(dev, tmp_path):

@@ -228,9 +228,12 @@ def main(argv=None):
     reducer = None
     if world > 1:
         import torch.distributed as dist
+        from gipvit.dist import RcclReducer, comm_setup
+        comm = comm_setup(world)                               # CUs left to RCCL's channels; the library sizes its launches for the rest
         dist.init_process_group("nccl", device_id=dev)         # RCCL
-        from gipvit.dist import RcclReducer
         reducer = RcclReducer()
+        if primary:
+            _logger.info("data parallel over %d ranks (RCCL): %d CUs left to communication, launches sized for %d", world, comm["comm_cus"], comm["cu_budget"])
     torch.manual_seed(args.seed + rank)                        # utils.random_seed(seed, rank), train.py:467
 
     ignored = [e["flags"][-1] for e in REFERENCE_FLAGS if not e["used"] and e["flags"][-1].startswith("-")
@@ -278,7 +281,19 @@ def main(argv=None):
     elif args.dataset.startswith("tiles:") or args.data_dir:
         root = args.dataset[6:] if args.dataset.startswith("tiles:") else args.data_dir
         slides = D.scan_slides(root, args.target)
-        train_slides, eval_slides = D.select_fold(slides, args.test_fold, True), D.select_fold(slides, args.test_fold, False)
+        # the evaluation selection is needed only where an inference loader (or --supervised's re-split) will use it; --test_fold -1
+        # is the reference's documented "no validation" setting (train.py:367, datasets.py:284-287 give folds = []): such a run
+        # trains on every fold but 'test' / 'val' and skips validate() instead of failing on the empty selection
+        want_eval = not args.no_validate and (not args.dino or args.extract_features)
+        no_val_fold = args.test_fold in (-1, "-1")
+        train_slides = D.select_fold(slides, args.test_fold, True)
+        if args.supervised or (want_eval and not no_val_fold):
+            eval_slides = D.select_fold(slides, args.test_fold, False)       # raises when evaluation was asked for and no slide is in the fold
+        else:
+            eval_slides = []
+            if want_eval and primary:
+                _logger.info("--test_fold -1: no validation fold; validate() is skipped (reference train.py:367)")
+            want_eval = False
         if args.supervised:
             # train.py:715-717: --supervised re-splits the TEST-fold set 80 / 20 into train / eval
             import numpy as np
@@ -287,7 +302,7 @@ def main(argv=None):
             train_slides, eval_slides = [eval_slides[i] for i in perm[:k]], [eval_slides[i] for i in perm[k:]] or eval_slides
         source = D.TileFolder(root, B, transform, rank, world, args.seed, tile, n_tiles=args.n_patches_train, workers=args.workers,
                               slides=train_slides)
-        if not args.no_validate and (not args.dino or args.extract_features):
+        if want_eval:
             inf_loader = D.InferTiles(root, tile, args.tiles_per_iter, args.num_tiles, seed=args.seed, dataset_name=args.dataset,
                                       workers=args.workers, slides=eval_slides)
     else:
