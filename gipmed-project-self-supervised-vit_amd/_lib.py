@@ -75,6 +75,9 @@ GV_ATTN_MAX_SEG = 4
 gv_attention_fwd_varlen_args = _struct("gv_attention_fwd_varlen_args", [
     ("qkv", vp), ("o", vp), ("n_seg", i32), ("n_img", i32 * GV_ATTN_MAX_SEG), ("N", i32 * GV_ATTN_MAX_SEG), ("lse", vp * GV_ATTN_MAX_SEG),
     ("H", i32), ("scale", f32)])
+gv_attention_bwd_varlen_args = _struct("gv_attention_bwd_varlen_args", [
+    ("qkv", vp), ("o", vp), ("d_o", vp), ("dqkv", vp), ("n_seg", i32), ("n_img", i32 * GV_ATTN_MAX_SEG), ("N", i32 * GV_ATTN_MAX_SEG),
+    ("lse", vp * GV_ATTN_MAX_SEG), ("H", i32), ("scale", f32)])
 gv_expand_rows_args = _struct("gv_expand_rows_args", [("per_img", vp), ("row_img", vp), ("rows", vp), ("n_rep", i32), ("n_img", i32), ("T", i32)])
 GV_DW_GROUP_MAX = 4
 gv_dw_problem = _struct("gv_dw_problem", [("dY", vp), ("ldy", i64), ("X", vp), ("ldx", i64), ("dW", vp), ("ldw", i64), ("colsum_dy", vp),
@@ -131,7 +134,7 @@ ENTRY_POINTS = {
     "gv_patchify": gv_patchify_args, "gv_crop_resize": gv_crop_resize_args, "gv_crop_augment": gv_crop_augment_args, "gv_augment": gv_augment_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
     "gv_colsum_finalize": gv_colsum_finalize_args, "gv_ln_finalize": gv_ln_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
     "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args, "gv_expand_rows": gv_expand_rows_args, "gv_linear_dw_group": gv_linear_dw_group_args,
-    "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_fwd_varlen": gv_attention_fwd_varlen_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_cls_rows": gv_cls_rows_args,
+    "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_fwd_varlen": gv_attention_fwd_varlen_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_attention_bwd_varlen": gv_attention_bwd_varlen_args, "gv_cls_rows": gv_cls_rows_args,
     "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,
     "gv_dino_loss": gv_dino_loss_args, "gv_center_update": gv_center_update_args, "gv_softmax_lsce": gv_softmax_lsce_args,

@@ -15,26 +15,28 @@ import torch.distributed as dist
 
 
 def comm_setup(world: int, backend: str = "nccl") -> dict:
-    """Make room on the chip for RCCL before the process group AND the kernel library exist.  Every heavy launch of this build is
-    sized to one workgroup per CU holding the CU's whole register file and LDS, so RCCL's channel workgroups cannot co-reside
-    with them: with more than one rank, C = GIPVIT_COMM_CUS (default 8) compute units are left to communication -- the library
-    sizes its launches for 256 - C (GIPVIT_CU_BUDGET, read once when it is loaded) and RCCL is capped to C channels
-    (NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS; values already in the environment win).  Returns what was decided, for the
-    log / JSON line.  No-op at world size 1 and for the gloo rehearsal transport."""
+    """Optionally make room on the chip for RCCL before the process group AND the kernel library exist.  Every heavy launch of this
+    build is one workgroup per CU holding the CU's whole register file and LDS, so RCCL's channel workgroups cannot co-reside with
+    them.  GIPVIT_COMM_CUS = C > 0 leaves C compute units to communication: the library sizes its launches for 256 - C
+    (GIPVIT_CU_BUDGET, read once when it is loaded) and RCCL is capped to C channels (NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS;
+    values already in the environment win).  The DEFAULT is C = 0 -- no budget, RCCL's own channel count: measured on one GPU with
+    a communication stand-in (tools/comm_standin.py) the budget costs more than it saves at every C tried
+    (C = 8: 14.03 ms per step without it, 14.16 with it; launches sized for 248 CUs alone: +0.48 ms), because a 251-workgroup
+    launch that finds C CUs taken loses only its tail, while a launch sized for 256 - C loses panel height on every CU.
+    Returns what was decided, for the log / JSON line.  No-op at world size 1 and for the gloo rehearsal transport."""
     import os
     import sys
     info = {"comm_cus": 0, "cu_budget": int(os.environ.get("GIPVIT_CU_BUDGET", "256"))}
     if world <= 1 or backend != "nccl":
         return info
-    if "gipvit._lib" in sys.modules and "GIPVIT_CU_BUDGET" not in os.environ:
-        raise RuntimeError("comm_setup() must run before the kernel library is loaded (the CU budget is read once at load)")
-    c = int(os.environ.get("GIPVIT_COMM_CUS", "8"))
+    c = int(os.environ.get("GIPVIT_COMM_CUS", "0"))
     if c > 0:
+        if "gipvit._lib" in sys.modules and "GIPVIT_CU_BUDGET" not in os.environ:
+            raise RuntimeError("comm_setup() must run before the kernel library is loaded (the CU budget is read once at load)")
         os.environ.setdefault("GIPVIT_CU_BUDGET", str(256 - c))
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(c))
         os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(c, 4)))
-    info.update(comm_cus=c, cu_budget=int(os.environ["GIPVIT_CU_BUDGET"]) if c > 0 else 256,
-                nccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS"))
+    info.update(comm_cus=c, cu_budget=int(os.environ.get("GIPVIT_CU_BUDGET", "256")), nccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS"))
     return info
 
 

@@ -246,6 +246,7 @@ class VitGroup:
         # CLS-only last block (VitRunner.cls_last): buffers over the n_img CLS rows, allocated on first use (alloc_cls)
         self.c_o = None
         self.D_ = D
+        self.prepared = False     # VitRunner.prepare_backward has zeroed this group's backward scratch for the coming backward
         self.dropout, self.tmp = None, None   # --drop: (p, step seed) and the f32 branch-output buffer of the unfused residual adds (set_dropout)
         self.rs = None            # stochastic depth: f32 [depth, 2, T] row factors of the attention / MLP branch (set_drop)
         self.drop_img = None      # ... and the per-image factors they were expanded from
@@ -460,6 +461,18 @@ class VitRunner:
             ops.linear(G.c_h, W.w(b + "mlp.fc2.weight"), G.c_xc, n, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
                        bias=W.f(b + "mlp.fc2.bias"), resid=G.c_xb, row_scale=rs_m)
 
+    def prepare_backward(self, G: VitGroup):
+        """Zero the backward scratch that is accumulated into or only partly written: the residual gradient (the final norm's backward
+        writes the CLS rows), and the attention-output gradient of the CLS-only last block / the first dY buffer otherwise.  Stream-
+        ordered fills with no input: an engine may issue them early on its side stream (DinoEngine does, beside the forward pass)."""
+        G.g.zero_()
+        if self._cls_tail(G):
+            G.alloc_cls()
+            G.do.zero_()
+        else:
+            (G.gb3 if (self.group_dw and ((self.depth - 1) & 1)) else G.gb).zero_()
+        G.prepared = True
+
     def _fin3(self, dgamma, dbeta, dbias):
         ops.ln_finalize(self.partials, L.LN_PARTIAL_BLOCKS, self.D, dgamma, dbeta, dbias)
 
@@ -483,9 +496,9 @@ class VitRunner:
         sets = ((G.gb, G.gb2, G.dh, G.dqkv), (G.gb3, G.gb4, G.dh_b, G.dqkv_b))      # per block parity: dY of the MLP / attention half, dh, dqkv
         gb_first = sets[(self.depth - 1) & 1][0] if grouped else G.gb
         cls_tail = self._cls_tail(G)          # the last block ran its projection / MLP on the CLS rows only (forward): so does its backward
-        G.g.zero_()
-        if not cls_tail:
-            gb_first.zero_()
+        if not G.prepared:
+            self.prepare_backward(G)
+        G.prepared = False
         xl = G.x[2 * self.depth]
         # stochastic depth: the bf16 gradient handed to a branch carries that branch's row factor (rs[i, 0] attention, rs[i, 1] MLP)
         rs = G.rs
@@ -609,11 +622,9 @@ class VitRunner:
                        W.g(b + "norm2.weight"), W.g(b + "norm2.bias"), W.g(b + "attn.proj.bias"),
                        dx_of=(G.c_dh, W.w(b + "mlp.fc1.weight"), 4 * D), gb_scale=None if rs is None else G.drop_img[i, 0], rows=n, g=G.c_g)
                 ops.linear(G.c_gb_att, W.w(b + "attn.proj.weight"), G.c_do, n, D, D, trans_b=True)
-                G.do.zero_()
-                G.scatter_cls(G.c_do, G.do)
+                G.scatter_cls(G.c_do, G.do)           # (G.do was zeroed by prepare_backward)
                 G.scatter_cls(G.c_g, G.g)                 # (G.g was zeroed above)
-                for sg in G.segs:
-                    ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(dqkv))
+                ops.attention_bwd_varlen(G.qkv[i], G.o[i], G.do, dqkv, [(sg.n_img, sg.N, sg.lse[i]) for sg in G.segs], H, self.scale)
                 ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
                        W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
                        dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])
@@ -639,8 +650,7 @@ class VitRunner:
             if dp:
                 drop_branch_grad(gb_att, i, 1, W.g(b + "attn.proj.bias"))
             ops.linear(gb_att, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
-            for sg in G.segs:
-                ops.attention_bwd(sg.rows(G.qkv[i]), sg.rows(G.o[i]), sg.rows(G.do), sg.lse[i], sg.n_img, sg.N, H, self.scale, dqkv=sg.rows(dqkv))
+            ops.attention_bwd_varlen(G.qkv[i], G.o[i], G.do, dqkv, [(sg.n_img, sg.N, sg.lse[i]) for sg in G.segs], H, self.scale)
             join(done_grp[par ^ 1])                       # block i + 1's group read gb_next (its MLP-half dY)
             ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
                    W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if (i > 0 and not dp) else None,
@@ -858,7 +868,7 @@ class DinoEngine:
         # the teacher's forward runs on the side stream beside the student's; GIPVIT_TEACHER_SIDE=0 queues it in front instead (A/B runs)
         self._teacher_on_side = os.environ.get("GIPVIT_TEACHER_SIDE", "1") != "0"
         if torch.device(device).type == "cuda":
-            self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_fork, self._ev_join, self._ev_zero = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         # contiguous arena range of every block's weight-decayed matrices (arena order = backward order)
         self._block_range = {}
         for i in range(ARCHS[arch]["depth"]):
@@ -944,8 +954,6 @@ class DinoEngine:
         a = self.arena
         mj, mn = micro
         first, last = mj == 0, mj == mn - 1
-        if first:
-            a.g.zero_()
         t_src, t_win, s_src, s_win = tiles_u8, [self.gwins], tiles_u8, self.s_wins
         if boxes is not None and fill is not None:
             raise ValueError("fill boxes are tile coordinates: they cannot be combined with re-cut random crops (boxes)")
@@ -977,9 +985,20 @@ class DinoEngine:
         # side stream beside the student forward (fills the tail of each other's kernels)
         side = self.vit.side if tiles_u8.is_cuda else None
         t_side = side if self._teacher_on_side else None
-        if t_side is not None:
+        # fills nothing in the forward depends on (the gradient arena, the backward's zero-initialised scratch) go to the side
+        # stream, beside the forward pass; the main stream picks their event up before the head backward
+        if side is not None:
             main = torch.cuda.current_stream()
             self._ev_fork.record(main); side.wait_event(self._ev_fork)
+            with torch.cuda.stream(side):
+                if first:
+                    a.g.zero_()
+                self.vit.prepare_backward(self.g_stu)
+                self._ev_zero.record(side)
+        else:
+            if first:
+                a.g.zero_()
+        if t_side is not None:
             with torch.cuda.stream(side):
                 self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats, fill=fill)
                 self.head.forward(self.tH, self.wn_t, self.hb_t)
@@ -1003,6 +1022,8 @@ class DinoEngine:
                 self.loss.copy_(self._loss_acc / mn); self.center_sum.copy_(self._center_acc)
         if last:
             self.reducer.reduce_tensor(self.center_sum)
+        if side is not None:
+            main.wait_event(self._ev_zero)
         self.head.backward(self.sH, self.wn_s, self.hb_s, self.train_last_layer, side=side)
         if not last:        # more micro-batches follow: gradients keep accumulating locally
             self.vit.backward(self.sW, self.g_stu, self.hb_s.dfeats)

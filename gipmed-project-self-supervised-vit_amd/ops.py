@@ -272,6 +272,31 @@ def attention_bwd(qkv, o, d_o, lse, n_img: int, N: int, H: int, scale: float, dq
     return dqkv
 
 
+def attention_bwd_varlen(qkv, o, d_o, dqkv, segments, H: int, scale: float):
+    """Backward of all segments of a token-concatenated row space in one call: ``segments`` = [(n_img, N, lse), ...] as for
+    attention_fwd_varlen; qkv / dqkv [T, 3 H 64], o / d_o [T, H 64].  bf16: gv_attention_bwd_varlen; the fp32 operand mode runs
+    one call per segment."""
+    if qkv.dtype != bf16 or len(segments) > L.GV_ATTN_MAX_SEG:
+        row = 0
+        for n_img, N, lse in segments:
+            r = slice(row, row + n_img * N)
+            attention_bwd(qkv[r], o[r], d_o[r], lse, n_img, N, H, scale, dqkv=dqkv[r])
+            row += n_img * N
+        return dqkv
+    if not (o.dtype == d_o.dtype == dqkv.dtype == qkv.dtype):
+        raise TypeError("attention_bwd_varlen: qkv / o / d_o / dqkv must share one dtype")
+    a = L.gv_attention_bwd_varlen_args()
+    a.qkv, a.o, a.d_o, a.dqkv, a.n_seg, a.H, a.scale = qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), dqkv.data_ptr(), len(segments), H, scale
+    rows = 0
+    for i, (n_img, N, lse) in enumerate(segments):
+        assert lse.dtype == f32 and lse.numel() >= n_img * H * N
+        a.n_img[i], a.N[i], a.lse[i] = n_img, N, lse.data_ptr()
+        rows += n_img * N
+    assert all(t.shape[0] >= rows and t.is_contiguous() for t in (qkv, o, d_o, dqkv))
+    L.call("gv_attention_bwd_varlen", a, _stream())
+    return dqkv
+
+
 def expand_rows(per_img, row_img, rows, n_rep: int, n_img: int, T: int):
     """rows[r, t] = per_img[r, row_img[t]]: per-image stochastic-depth factors -> one factor per token row (n_rep branches)."""
     L.call("gv_expand_rows", L.gv_expand_rows_args(per_img.data_ptr(), row_img.data_ptr(), rows.data_ptr(), n_rep, n_img, T), _stream())

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 8
+#define GV_ABI_VERSION 9
 enum { GV_HYP_LR = 0, GV_HYP_WD, GV_HYP_BC1, GV_HYP_BC2, GV_HYP_TEACHER_MOM, GV_HYP_GRAD_SCALE,
        GV_HYP_TEACHER_TEMP, GV_HYP_STUDENT_TEMP, GV_HYP_COUNT };
 
@@ -354,7 +354,7 @@ int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream);
  * holds n_img[i] images of N[i] tokens, its rows start where segment i - 1 ends, qkv / o cover all segments, lse[i] is
  * segment i's f32 [n_img[i], H, N[i]].  A long (128 < N <= 224) + a short (32 < N <= 64) segment run as ONE launch
  * (the short pairs fill the long launch's last, half-empty round of workgroups); any other mix runs one launch per segment.
- * (The backward stays one call per segment: its long class holds a CU's LDS alone, so a merged launch gains nothing.)       */
+ * (gv_attention_bwd_varlen below takes the same segment table.)                                                              */
 #define GV_ATTN_MAX_SEG 4
 typedef struct {
     const void* qkv; void* o;
@@ -370,6 +370,18 @@ typedef struct {
     int32_t n_img, N, H; float scale;
 } gv_attention_bwd_args;
 int gv_attention_bwd(const gv_attention_bwd_args* a, void* stream);
+
+/* Varlen backward: the segment table of gv_attention_fwd_varlen (segment i: n_img[i] images of N[i] tokens, rows back to back in
+ * qkv / o / d_o / dqkv; lse[i] as the forward left it).  One CALL for the multi-crop row space; inside, each length class runs as
+ * its own launch: the long class (N > 64) holds a CU's LDS alone (114 - 142 KB per (image, head) pair) while the short classes
+ * run 4 - 5 workgroups per CU, so a shared launch geometry would cost the short pairs their occupancy.  */
+typedef struct {
+    const void* qkv; const void* o; const void* d_o; void* dqkv;
+    int32_t n_seg; int32_t n_img[GV_ATTN_MAX_SEG]; int32_t N[GV_ATTN_MAX_SEG];
+    const float* lse[GV_ATTN_MAX_SEG];
+    int32_t H; float scale;
+} gv_attention_bwd_varlen_args;
+int gv_attention_bwd_varlen(const gv_attention_bwd_varlen_args* a, void* stream);
 
 /* ---- token assembly (vit.pyc@L235-246 prepare_tokens: CLS row) ---------
  * x[i*N + 0, :] = cls[:] + pos[0, :] for every image i.                    */

@@ -22,11 +22,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), f"{name} declared in gipvit.h but not exported"
     bound = set(_lib.ENTRY_POINTS) | set(_lib.PLAIN_SYMBOLS)
     assert declared == bound, (declared - bound, bound - declared)
-    assert _lib.lib.gv_version() == 8 and _lib.lib.gv_target() == b"gfx950" and _lib.lib.gv_act_format() == 0
+    assert _lib.lib.gv_version() == 9 and _lib.lib.gv_target() == b"gfx950" and _lib.lib.gv_act_format() == 0
     # the float16 build (-DGV_ACT_F16, --amp --amp-dtype float16) is the same ABI (looked at from a process of its own: one process
     # loads one of the two libraries)
     code = ("import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); missing = [n for n in sys.argv[2:] if not hasattr(l, n)]; "
-            "assert not missing, missing; assert l.gv_version() == 8 and l.gv_act_format() == 1")
+            "assert not missing, missing; assert l.gv_version() == 9 and l.gv_act_format() == 1")
     r = subprocess.run([sys.executable, "-c", code, os.path.join(os.path.dirname(_lib.LIB_PATH), "libgipvit_hip_f16.so")] + sorted(declared),
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-600:]

@@ -597,6 +597,36 @@ def test_attention_fwd_varlen(dev, segs):
     close(out[:n * N], ref, 2e-2, 2e-2, "varlen vs sdpa")
 
 
+@pytest.mark.parametrize("segs", [[(6, 197), (20, 37)], [(9, 37), (3, 197)], [(2, 224), (7, 64), (3, 17)], [(3, 100)]])
+def test_attention_bwd_varlen(dev, segs):
+    """gv_attention_bwd_varlen: the backward of a token-concatenated multi-crop row space in one call (the forward's segment table).
+    Checked against the fp32 torch expression (autograd through softmax(q k^T scale) v per segment) on the WHOLE mixed-length row
+    space, against the per-segment calls bit for bit, and rows outside the segments stay untouched."""
+    o, H, scale = ops(), 6, 0.125
+    g = torch.Generator().manual_seed(23)
+    T = sum(n * N for n, N in segs)
+    qkv = torch.randn(T + 2, 3 * H * 64, generator=g).to(dev).to(bf16)
+    d_o = torch.randn(T + 2, H * 64, generator=g).to(dev).to(bf16)
+    out = torch.empty(T + 2, H * 64, dtype=bf16, device=dev)
+    lses = [torch.empty(n, H, N, dtype=f32, device=dev) for n, N in segs]
+    table = [(n, N, l) for (n, N), l in zip(segs, lses)]
+    o.attention_fwd_varlen(qkv, out, table, H, scale)
+    dqkv = torch.full((T + 2, 3 * H * 64), 5.0, dtype=bf16, device=dev)
+    o.attention_bwd_varlen(qkv, out, d_o, dqkv, table, H, scale)
+    assert float(dqkv[T:].float().min()) == 5.0 and float(dqkv[T:].float().max()) == 5.0
+    row = 0
+    for (n, N), l in zip(segs, lses):
+        r = slice(row, row + n * N)
+        ref_seg = o.attention_bwd(qkv[r], out[r], d_o[r], l, n, N, H, scale)
+        assert torch.equal(dqkv[r], ref_seg), (n, N)
+        x = qkv[r].float().view(n, N, 3, H, 64).requires_grad_(True)
+        q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+        y = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(n * N, H * 64)
+        y.backward(d_o[r].float())
+        close(dqkv[r], x.grad.reshape(n * N, 3 * H * 64), 3e-2, 2e-2 * max(float(x.grad.abs().max()), 1.0), f"varlen backward vs fp32 torch, segment {(n, N)}")
+        row += n * N
+
+
 @pytest.mark.parametrize("dt", [bf16, f32])
 def test_dropout_kernels(dev, dt):
     """gv_dropout / gv_dropout_add: the counter-based keep mask of (seed, element index) equals the oracle's numpy restatement bit for

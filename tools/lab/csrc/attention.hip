@@ -63,7 +63,11 @@ template <int NKT>
 struct FwdCfg {
     // long sequences: 16 queries per wave and round (the score registers halve, two 8-wave workgroups
     // fit a CU and cover each other's load phases); short ones: 32 queries per wave
+#ifdef GV_LAB_ATTN_QT2       // lab: 32 queries per wave at every length (half the K / V fragment reads per query, one workgroup per CU)
+    static constexpr int QT = 2;
+#else
     static constexpr int QT = NKT >= 14 ? 1 : 2;                  // 16-query tiles per wave and round
+#endif
     static constexpr int NQB = (NKT + QT - 1) / QT;               // query blocks of 16 QT rows
     static constexpr int NW = NQB >= 5 ? 8 : 4;                   // waves per workgroup
     static constexpr int PAIRS = NQB >= NW ? 1 : (NW / NQB >= 1 ? NW / NQB : 1);
@@ -569,24 +573,6 @@ extern "C" int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream) {
     GV_REQUIRE(a->n_img > 0 && a->H > 0 && a->N > 0 && a->N <= 288, GV_E_SHAPE, "gv_attention_fwd: need 0 < N <= 288 (got %d)", a->N);
     GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16), GV_E_ALIGN, "gv_attention_fwd: qkv/o must be 16-byte aligned");
     return launch_fwd_any(a, (hipStream_t)stream);
-}
-
-extern "C" int gv_attention_bwd_varlen(const gv_attention_bwd_varlen_args* v, void* stream) {
-    GV_REQUIRE(v && v->qkv && v->o && v->d_o && v->dqkv, GV_E_NULL, "gv_attention_bwd_varlen: null pointer");
-    GV_REQUIRE(v->n_seg >= 1 && v->n_seg <= GV_ATTN_MAX_SEG && v->H > 0, GV_E_SHAPE, "gv_attention_bwd_varlen: 1..%d segments, H > 0", GV_ATTN_MAX_SEG);
-    long row = 0;
-    for (int i = 0; i < v->n_seg; ++i) {
-        GV_REQUIRE(v->n_img[i] > 0 && v->N[i] > 0 && v->N[i] <= 288 && v->lse[i], GV_E_SHAPE, "gv_attention_bwd_varlen: segment %d: need n_img > 0, 0 < N <= 288, lse", i);
-        gv_attention_bwd_args seg;
-        seg.qkv = (const char*)v->qkv + row * 3 * v->H * 64 * 2;
-        seg.o = (const char*)v->o + row * v->H * 64 * 2;
-        seg.d_o = (const char*)v->d_o + row * v->H * 64 * 2;
-        seg.dqkv = (char*)v->dqkv + row * 3 * v->H * 64 * 2;
-        seg.lse = v->lse[i]; seg.n_img = v->n_img[i]; seg.N = v->N[i]; seg.H = v->H; seg.scale = v->scale;
-        if (int rc = gv_attention_bwd(&seg, stream)) return rc;
-        row += (long)v->n_img[i] * v->N[i];
-    }
-    return GV_OK;
 }
 
 extern "C" int gv_attention_bwd(const gv_attention_bwd_args* a, void* stream) {

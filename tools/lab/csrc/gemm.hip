@@ -182,9 +182,22 @@ int dw8_pick_slices(int tiles, int ktiles, long mn_floats, long workspace_bytes)
 template <bool SWAP>
 int launch_dw8(const Dw8P& q, float* C, long ldc, int M, int N, hipStream_t s) {
     auto kern = dw8_kernel<SWAP>;
+#ifdef GV_DW8_LAB     // tuning lab: ablation variants by environment (tools/dw8_lab.sh)
+    {
+        const char* ev = getenv("GIPVIT_DW8_VAR");
+        const int var = ev ? atoi(ev) : 0;
+        switch (var) {
+            case 1: kern = dw8_kernel<SWAP, 1>; break; case 2: kern = dw8_kernel<SWAP, 2>; break; case 4: kern = dw8_kernel<SWAP, 4>; break;
+            case 8: kern = dw8_kernel<SWAP, 8>; break; case 16: kern = dw8_kernel<SWAP, 16>; break; case 24: kern = dw8_kernel<SWAP, 24>; break;
+            case 32: kern = dw8_kernel<SWAP, 32>; break; case 56: kern = dw8_kernel<SWAP, 56>; break;
+            default: break;
+        }
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DW8_LDS);
+    }
+#endif
     static GvLdsOptIn opt_in;
     if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, DW8_LDS, "gemm(dw8)")) return rc;
-    const int th = gvtime::enabled() ? gvtime::begin(SWAP ? "dw8_kernel<true>" : "dw8_kernel<false>", 2.0 * M * N * q.K, 2.0 * q.K * ((double)M + N) + 8.0 * M * N, s) : -1;
+    const int th = gvtime::enabled() ? gvtime::begin(SWAP ? "dw8_kernel<true, 0>" : "dw8_kernel<false, 0>", 2.0 * M * N * q.K, 2.0 * q.K * ((double)M + N) + 8.0 * M * N, s) : -1;
     hipLaunchKernelGGL(kern, dim3(q.tiles_p * q.tiles_q * q.ksplit), dim3(512), DW8_LDS, s, q);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK("gv_linear(dw8)");
@@ -195,6 +208,9 @@ int launch_dw8(const Dw8P& q, float* C, long ldc, int M, int N, hipStream_t s) {
     return GV_OK;
 }
 
+#ifdef GV_DW8_STAMPS
+unsigned long long* g_dw8_dbg = nullptr;
+#endif
 int try_dw8(const gv_linear_args* a, hipStream_t s) {
     if (!(a->trans_a && a->trans_b && a->c_is_f32 && a->epilogue == GV_EPI_ACCUM && a->workspace && gv_aligned(a->workspace, 16))) return -1;
     if (a->alpha != 0.f && a->alpha != 1.f) return -1;
@@ -204,6 +220,9 @@ int try_dw8(const gv_linear_args* a, hipStream_t s) {
     if (!normal && !swapped) return -1;
     Dw8P q;
     q.K = a->K; q.slab = (float*)a->workspace; q.colsum = a->colsum_a;
+#ifdef GV_DW8_STAMPS
+    { static unsigned long long* dbg = nullptr; if (!dbg) { (void)hipMalloc(&dbg, 256 * 8 * 8 * 8); } q.dbg = dbg; g_dw8_dbg = dbg; }
+#endif
     if (normal) { q.P = (const bf16*)a->A; q.ldp = a->lda; q.Pn = a->M; q.Q = (const bf16*)a->B; q.ldq = a->ldb; q.Qn = a->N; }
     else { q.P = (const bf16*)a->B; q.ldp = a->ldb; q.Pn = a->N; q.Q = (const bf16*)a->A; q.ldq = a->lda; q.Qn = a->M; }
     q.tiles_p = q.Pn / 128; q.tiles_q = q.Qn / 384;
@@ -243,6 +262,9 @@ extern "C" int64_t gv_workspace_bytes(int32_t op, const void* args) {
     g_plan = false;
     return rc == GV_OK ? (int64_t)g_plan_bytes : -1;
 }
+#ifdef GV_DW8_STAMPS   // tuning-lab build only (tools/dw_bench.py)
+extern "C" int gv_dw8_dbg_read(unsigned long long* host) { if (!g_dw8_dbg) return -1; return (int)hipMemcpy(host, g_dw8_dbg, 256 * 8 * 8 * 8, hipMemcpyDeviceToHost); }
+#endif
 
 // ---- live per-kernel timing (timing.h; gv_linear_timing / gv_linear_timing_read of include/gipvit.h)
 namespace {
@@ -458,6 +480,9 @@ extern "C" int gv_linear_dw_group(const gv_linear_dw_group_args* a, void* stream
                 d.P = (const bf16*)pr.dY; d.ldp = pr.ldy; d.Pn = pr.M; d.Q = (const bf16*)pr.X; d.ldq = pr.ldx; d.Qn = pr.N;
                 d.K = a->K; d.tiles_p = pr.M / 128; d.tiles_q = pr.N / 384; d.ksplit = S; d.k_per_split = per * 64;
                 d.slab = a->workspace + slab_floats; d.colsum = pr.colsum_dy;
+#ifdef GV_DW8_STAMPS
+                d.dbg = nullptr;
+#endif
                 slab_floats += (long)S * pr.M * pr.N;
                 G8.tile_base[q] = tb; tb += d.tiles_p * d.tiles_q;
                 flops += 2.0 * pr.M * pr.N * a->K; bytes += 2.0 * a->K * ((double)pr.M + pr.N) + 8.0 * pr.M * pr.N;

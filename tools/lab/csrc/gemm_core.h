@@ -3,8 +3,14 @@
 #pragma once
 #include "gv_common.h"
 
-// (The tuning lab's ablation bits, s_memtime stamps and experimental k-loop schedules live in the lab copy of this file,
-// tools/lab/csrc/gemm_core.h; gv_linear rejects any epilogue bit outside the documented mask.)
+// Tuning-lab switches (ablation bits 20-22 of GemmP::epi, s_memtime stamps, experimental k-loop schedules 10 / 20)
+// exist only in builds made with -DGV_GEMM_LAB (tools/gemm_lab.hip); the production library compiles them out and
+// gv_linear rejects any epilogue bit outside the documented mask.
+#ifdef GV_GEMM_LAB
+#define GV_LAB_BIT(g, bit) (((g).epi & (1 << (bit))) != 0)
+#else
+#define GV_LAB_BIT(g, bit) false
+#endif
 
 namespace gvgemm {
 
@@ -232,6 +238,21 @@ __device__ __forceinline__ Item make_item(const GemmP& g, const Walk& w, int idx
     return it;
 }
 
+#if defined(GV_GEMM_STAMPS) && !defined(GV_GEMM_LAB)
+#error "GV_GEMM_STAMPS is a tuning-lab option: build with -DGV_GEMM_LAB"
+#endif
+#ifdef GV_GEMM_STAMPS
+__device__ __forceinline__ unsigned long long gv_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define GV_STAMP(var) const unsigned long long var = gv_stamp()
+#else
+#define GV_STAMP(var)
+#endif
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -249,10 +270,19 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int li16 = lane & 15, gq = lane >> 4;
+#ifdef GV_GEMM_STAMPS
+    GV_STAMP(t_kernel0);
+#endif
 
     // SCHED 20 (lab): a workgroup that walks several items issues the NEXT item's first ring stage before the
     // epilogue of the current one (the epilogue image then lives in the other stage only)
-    static_assert(C::SCHED >= 0 && C::SCHED <= 3, "k-loop schedule");
+    #ifdef GV_GEMM_LAB
+    constexpr bool XPF = C::SCHED == 20 && C::NSTAGE == 2 && !ATOMIC;
+#else
+    static_assert(C::SCHED != 10 && C::SCHED != 20, "k-loop schedules 10 / 20 are tuning-lab builds (-DGV_GEMM_LAB)");
+    constexpr bool XPF = false;
+#endif
+    bool prefetched = false;
     for (int it_i = 0, idx = wk.first; it_i < wk.count; ++it_i, idx += wk.stride) {
         const Item it = make_item<C>(g, wk, idx);
         TileSrc<TA, BM, BK, C::NW> srcA;
@@ -262,7 +292,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
         // ---- the LDS-DMA ring runs PD k-steps ahead of the MFMAs
         int l_k = 0, l_stage = 0;
         auto issue = [&]() {
-            if (l_k < it.nt) {
+            if (l_k < it.nt && !GV_LAB_BIT(g, 21)) {
                 GV_LDS char* st = smem + l_stage * C::STAGE;
                 const int k0 = it.kbeg + l_k * BK;
                 srcA.issue(g.lda, k0, it.kend, st, wave);
@@ -274,7 +304,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
         // the same, one piece at a time (SCHED >= 2 spreads a step's pieces between its MFMAs)
         bool p_live = false; GV_LDS char* p_st = smem; int p_k0 = 0;
         auto issue_begin = [&]() {
-            p_live = l_k < it.nt;
+            p_live = l_k < it.nt && !GV_LAB_BIT(g, 21);
             p_st = smem + l_stage * C::STAGE; p_k0 = it.kbeg + l_k * BK;
             ++l_k;
             l_stage = (l_stage + 1 == NSTAGE) ? 0 : l_stage + 1;
@@ -284,8 +314,11 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
             if (p < C::A_PPW) srcA.issue_one(p, g.lda, p_k0, it.kend, p_st, wave);
             else srcB.issue_one(p - C::A_PPW, g.ldb, p_k0, it.kend, p_st + C::A_BYTES, wave);
         };
+        if (XPF && prefetched) { l_k = 1; l_stage = 1; }      // stage 0 was issued during the previous item's epilogue
+        else {
 #pragma unroll
-        for (int s = 0; s < PD; ++s) issue();
+            for (int s = 0; s < PD; ++s) issue();
+        }
 
         // ---- epilogue geometry (see below) and EARLY PREFETCH of its global operands: the
         // residual / pos / accumulate-into values and the saved pre-activation are loaded into
@@ -294,7 +327,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
         const int m0 = it.m0 + wm * FM * 16, n0 = it.n0 + wn * FN * 16;
         constexpr int IW = FN * 16;                     // image width (columns of this wave)
         constexpr int STRIDE = IW + 4;                  // f32 row stride, +4 breaks bank conflicts
-        constexpr int IMG_BYTES = C::LDS / C::NW;      // this wave's share of the epilogue image space
+        constexpr int IMG_BYTES = (XPF ? C::STAGE : C::LDS) / C::NW;      // this wave's share of the epilogue image space
         constexpr int ROWS_FIT = IMG_BYTES / (STRIDE * 4);
         constexpr int IB = ROWS_FIT >= FM * 16 ? FM : (ROWS_FIT >= 32 && FM % 2 == 0 ? 2 : 1);   // 16-row blocks per pass
         static_assert(16 * STRIDE * 4 <= IMG_BYTES, "one 16-row block of the image must fit the wave's share");
@@ -307,7 +340,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
         const int lcol = (LPR >= 64 ? lane : lane % LPR) * W;
         const int epi = EPI >= 0 ? EPI : g.epi;
         const int N = g.N, M = g.M;
-        constexpr bool PREFETCH = !ATOMIC && EPI >= 0 && (EPI & (GV_EPI_RESID | GV_EPI_POS | GV_EPI_ACCUM | GV_EPI_DGELU)) != 0 && FM <= 4;
+        constexpr bool PREFETCH = !ATOMIC && EPI >= 0 && (EPI & (GV_EPI_RESID | GV_EPI_POS | GV_EPI_ACCUM | GV_EPI_DGELU)) != 0 && FM <= 4 && C::SCHED != 10;
         constexpr bool BIAS_EARLY = !ATOMIC && EPI >= 0 && (EPI & GV_EPI_BIAS) != 0 && CPI == 1;
         f32x4 pre_b[W / 4 > 0 ? W / 4 : 1];
         if constexpr (BIAS_EARLY) {
@@ -355,8 +388,68 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
         for (int i = 0; i < FM; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const bf16x8 ones = bf16x8{(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
 
+#ifdef GV_GEMM_STAMPS
+        unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+        GV_STAMP(t_loop0);
+#endif
         int c_stage = 0;
+#ifdef GV_GEMM_LAB
+        if constexpr (C::SCHED == 10) {
+            // ---- PING-PONG k-loop (lab): the workgroup's two halves of wave rows (SIMD partners: waves w and w + NW/2)
+            // alternate roles every half step: while one group issues the LDS-DMA of step t + PD and reads its
+            // fragments of step t, the other runs the MFMAs of the step it read before.  Two barriers per step;
+            // before the second one every wave has waited for its pieces of step t + 1 (counted vmcnt) and for
+            // its fragment reads (lgkmcnt(0)), so the next reader finds the stage landed and the next LDS-DMA
+            // finds its target stage (last read one step ago) free.
+            static_assert(C::WM % 2 == 0 && C::KS == 1 && PD >= 2, "ping-pong: an even number of wave rows, BK = 32");
+            const int grp = wm / (C::WM / 2);
+            bf16x8 pa[FM], pb[FN];
+            auto reads = [&](int stage) {
+                GV_LDS char* cur = smem + stage * C::STAGE;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) pb[j] = read_frag<TB, BN, BK>(cur + C::A_BYTES, wn * FN + j, 0, lane);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) pa[i] = read_frag<TA, BM, BK>(cur, wm * FM + i, 0, lane);
+            };
+            auto mfmas = [&]() {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = GV_MFMA_16x16x32(pb[j], pa[i], acc[i][j]);
+            };
+            auto wait_young = [&](int young) {
+                if (young >= 2) wait_vmcnt<C::GLDS * 2>();
+                else if (young == 1) wait_vmcnt<C::GLDS>();
+                else wait_vmcnt<0>();
+            };
+            wait_young(min(PD, it.nt) - 1);                  // step 0 landed (mine)
+            __builtin_amdgcn_s_barrier();
+            // one code path for both halves; the second half runs it one barrier late (and the first half
+            // takes one extra barrier at the end), so its memory phase lines up with the other's MFMA phase
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            for (int t = 0; t < it.nt; ++t) {
+                issue();
+                reads(c_stage);
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // fragments in registers before the barrier
+                wait_young(max(0, min(PD - 1, it.nt - 2 - t)));   // my pieces of step t + 1 landed; t + 2.. may fly
+                // sched_barrier: hipcc moves register-only MFMAs across s_barrier / s_waitcnt otherwise, which
+                // would put both halves' MFMAs into the same phase
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                mfmas();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+            }
+            if (grp == 0) __builtin_amdgcn_s_barrier();
+        } else
+#endif
         for (int t = 0; t < it.nt; ++t) {
+            GV_STAMP(ts0);
             // this step's pieces (mine) landed: everything but the younger in-flight steps
             {
                 const int young = min(PD - 1, it.nt - 1 - t);
@@ -365,13 +458,25 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
                 else if (PD >= 2 && young == 1) wait_vmcnt<C::GLDS * 1>();
                 else wait_vmcnt<0>();
             }
+            GV_STAMP(ts1);
             __builtin_amdgcn_s_barrier();     // everybody's pieces landed; last step's stage is free
-            if constexpr (C::SCHED == 0) issue();
+            GV_STAMP(ts2);
+            if constexpr (C::SCHED == 0 || C::SCHED == 20) issue();
+            GV_STAMP(ts3);
             GV_LDS char* cur = smem + c_stage * C::STAGE;
             // all fragment reads of the stage are issued up front (KS * (FM + FN) ds_read_b128 /
             // tr reads); the MFMAs then run back-to-back behind the compiler's counted lgkmcnt(N)
             // instead of exposing the LDS latency once per small read group.
             bf16x8 fa[C::KS][FM], fb[C::KS][FN];
+            if (GV_LAB_BIT(g, 22)) {     // lab ablation: fragments from registers, no LDS reads
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) { fb[ks][j] = fb[0][0]; asm volatile("" : "+v"(fb[ks][j])); }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) { fa[ks][i] = fb[0][0]; asm volatile("" : "+v"(fa[ks][i])); }
+                }
+            } else
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
 #pragma unroll
@@ -379,6 +484,9 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
 #pragma unroll
                 for (int i = 0; i < FM; ++i) fa[ks][i] = read_frag<TA, BM, BK>(cur, wm * FM + i, ks, lane);
             }
+#ifdef GV_GEMM_PIN_READS
+            __builtin_amdgcn_sched_barrier(0);   // keep every read ahead of the first MFMA
+#endif
             if constexpr (C::SCHED == 1) issue();
             if constexpr (C::SCHED == 2 || C::SCHED == 3) issue_begin();
             constexpr int GROUPS = C::KS * FM;                     // MFMA row groups of FN MFMAs each
@@ -415,7 +523,13 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
                 }
             }
             c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+#ifdef GV_GEMM_STAMPS
+            { GV_STAMP(ts4); c_wait += ts1 - ts0; c_bar += ts2 - ts1; c_issue += ts3 - ts2; c_comp += ts4 - ts3; }
+#endif
         }
+#ifdef GV_GEMM_STAMPS
+        GV_STAMP(t_loop1);
+#endif
         __builtin_amdgcn_s_barrier();   // every wave is done reading the ring: it is epilogue scratch now
         if constexpr (TA) {
             if (do_colsum && gq == 0) {       // csum[i][r]: column = lane&15 = m, every row identical
@@ -431,7 +545,22 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
         // The accumulators go through a per-wave LDS image so that every lane ends up with
         // ROW-CONTIGUOUS columns: bias / residual / aux loads and all stores (and atomics) are
         // then whole 128..256-B row segments instead of 16 scattered 32-B pieces per instruction.
-        GV_LDS float* img = (GV_LDS float*)(smem + wave * IMG_BYTES);
+        if constexpr (XPF) {
+            prefetched = false;
+            if (it_i + 1 < wk.count) {       // every wave is past the ring (barrier above): stage 0 is free for the next item
+                const Item nx = make_item<C>(g, wk, idx + wk.stride);
+                TileSrc<TA, BM, BK, C::NW> nA;
+                TileSrc<TB, BN, BK, C::NW> nB;
+                nA.setup(g.A, g.lda, nx.m0, g.M, wave, lane);
+                nB.setup(g.B, g.ldb, nx.n0, g.N, wave, lane);
+                if (!GV_LAB_BIT(g, 21)) {
+                    nA.issue(g.lda, nx.kbeg, nx.kend, smem, wave);
+                    nB.issue(g.ldb, nx.kbeg, nx.kend, smem + C::A_BYTES, wave);
+                }
+                prefetched = true;
+            }
+        }
+        GV_LDS float* img = (GV_LDS float*)(smem + (XPF ? C::STAGE : 0) + wave * IMG_BYTES);
         float* Cf = (float*)g.C;
         OutT* Cp = (OutT*)g.C;
         bool vec_path = true;
@@ -513,7 +642,8 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
                                 }
                                 v[q] += r[0]; v[q + 1] += r[1]; v[q + 2] += r[2]; v[q + 3] += r[3];
                             }
-                            if (ok) {
+                            if (GV_LAB_BIT(g, 20)) { asm volatile("" ::"v"(v[0]), "v"(v[W - 1])); }   // lab ablation: no store
+                            else if (ok) {
                                 if constexpr (W == 8) *(bf16x8*)(Cp + orow * g.ldc + n) = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
                                 else store4<OutT>(Cp + orow * g.ldc + n, v);
                             }
@@ -555,6 +685,16 @@ __device__ __forceinline__ void gemm_body_w(const GemmP& g, GV_LDS char* smem, c
         // store-data registers it reuses in the next k-loop with its own vmcnt(0) per k-step),
         // and let every wave leave its image before the next item's LDS-DMA overwrites it.
         if (it_i + 1 < wk.count) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); a wave that exits next needs no wait
+#ifdef GV_GEMM_STAMPS
+        {   // stamps leave through a buffer of their own (g.pos is unused by the lab shapes)
+            GV_STAMP(t_end);
+            if (lane == 0 && g.pos) {
+                float* o = (float*)g.pos + ((long)blockIdx.x * C::NW + wave) * 8;
+                o[0] = (float)c_wait; o[1] = (float)c_bar; o[2] = (float)c_issue; o[3] = (float)c_comp;
+                o[4] = (float)(t_loop1 - t_loop0); o[5] = (float)(t_end - t_loop1); o[6] = (float)(t_loop0 - t_kernel0); o[7] = (float)it.nt;
+            }
+        }
+#endif
         if (it_i + 1 < wk.count) __builtin_amdgcn_s_barrier();
     }
 }

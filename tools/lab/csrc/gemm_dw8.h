@@ -39,15 +39,30 @@ struct Dw8P {
     int tiles_p, tiles_q, ksplit, k_per_split;
     float* slab;         // [ksplit][rows][cols] f32, rows x cols = Pn x Qn (normal) or Qn x Pn (swapped)
     float* colsum;       // null, or += column sums of P (normal) / of Q (swapped)
+#ifdef GV_DW8_STAMPS
+    unsigned long long* dbg;
+#endif
 };
 
 constexpr int DW8_IMG = 64 * 128 * 2;
 constexpr int DW8_STAGE = 4 * DW8_IMG;
 constexpr int DW8_LDS = 2 * DW8_STAGE;
 
+#ifdef GV_DW8_STAMPS
+#define DW8_STAMP(v) const unsigned long long v = dw8_stamp()
+__device__ __forceinline__ unsigned long long dw8_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#else
+#define DW8_STAMP(v)
+#endif
 
 // one (tile, k-slice) item of problem g: tile tt of g.tiles_p x g.tiles_q, slice `slice`
-template <bool SWAP>      // (ablation variants of this body: tools/lab/csrc/gemm_dw8.h)
+template <bool SWAP, int VAR>      // VAR: tuning-lab ablation bits (GV_DW8_LAB builds only; the product instantiates 0)
 __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const int tt, GV_LDS char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,7 +96,11 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
         constexpr int X = decltype(Xc)::value, STG = decltype(Sc)::value, img = X >> 1, pc = X & 1;
         const unsigned dst = lds0 + STG * DW8_STAGE + img * DW8_IMG + pc * 1024;
         if constexpr (img == 0) glds16_s<0>(baseP + (unsigned long long)u * stepP, voffP[pc], dst);
+#ifdef GV_NT_DWX    // lab: the 384-wide operand is the saved forward activation (h, xn2, o, xn1): last use in the step
+        else glds16_s<(img - 1) * 256, true>(baseQ + (unsigned long long)u * stepQ, voffQ[pc], dst);
+#else
         else glds16_s<(img - 1) * 256>(baseQ + (unsigned long long)u * stepQ, voffQ[pc], dst);
+#endif
     };
     // ragged last K-tile of the slice / the dummy tiles behind it: rows past the slice read zeros
     auto issue_slow = [&](auto Xc, auto Sc, int u) {
@@ -142,7 +161,7 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
     wait_vmcnt<8>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();       // the second half runs one barrier late
+    if (wm == 1 && !(VAR & 4)) __builtin_amdgcn_s_barrier();       // the second half runs one barrier late
     __builtin_amdgcn_sched_barrier(0);
 
     // fragments are double-buffered in registers: phase p's MFMA cluster carries the LDS reads of phase p + 1
@@ -155,6 +174,10 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
         for (int i = 0; i < 4; ++i) fa[0][ks][i] = rd(ra[0][i] + ks * 8192);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);              // retired here, so that hipcc's counter model enters the loop clean
+#ifdef GV_DW8_STAMPS
+    unsigned long long c_rd = 0, c_is = 0, c_b1 = 0, c_mf = 0, c_b2 = 0;
+    DW8_STAMP(t_start);
+#endif
     // Phase (t, J): tile t in stage S = t & 1, fragments in fa[FA], fb[FB].
     //   load segment:  DMA issue, counted wait          | s_barrier |
     //   MFMA segment:  16 MFMAs + the fragment reads of phase (t, J) + 1 into the other register set, lgkmcnt(0) | s_barrier
@@ -169,17 +192,31 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
     auto phase = [&](auto Jc, auto Sc, auto FAc, auto FBc, int t) {
         constexpr int J = decltype(Jc)::value, S = decltype(Sc)::value, FA = decltype(FAc)::value, FB = decltype(FBc)::value;
         using SN = std::integral_constant<int, S ^ 1>;
+        DW8_STAMP(s1);
         // waits: J = 0 needs Q2(t) (8 t + 7) of 8 t + 16 out; J = 1 needs Q0(t + 1) (8 t + 11) of 8 t + 19; J = 2 needs
         // Q1(t + 1) (8 t + 13) of 8 t + 22
-        if constexpr (J == 0) { issue(SN{}, t + 1, I6{}, I7{}, IN{}); wait_vmcnt<8>(); }
+        if constexpr ((VAR & 8) != 0) {}
+        else if constexpr (J == 0) { issue(SN{}, t + 1, I6{}, I7{}, IN{}); wait_vmcnt<8>(); }
         else if constexpr (J == 1) { issue(Sc, t + 2, I0{}, I1{}, I2{}); wait_vmcnt<7>(); }
         else { issue(Sc, t + 2, I3{}, I4{}, I5{}); wait_vmcnt<8>(); }
+        DW8_STAMP(s2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        DW8_STAMP(s3);
+        if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
         // next phase's fragments
-        if constexpr (J < 2) {
+        if constexpr ((VAR & 16) != 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { fb[FB ^ 1][ks][j] = fb[FB][ks][j]; asm volatile("" : "+v"(fb[FB ^ 1][ks][j])); }
+                if constexpr (J == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { fa[FA ^ 1][ks][i] = fa[FA][ks][i]; asm volatile("" : "+v"(fa[FA ^ 1][ks][i])); }
+                }
+            }
+        } else if constexpr (J < 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -219,7 +256,10 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
         }
         // the reads go out EARLY in the cluster, one (J = 2: two) per MFMA gap -- hipcc sinks them behind the last MFMA otherwise
         // and the closing lgkmcnt(0) then exposes the whole LDS latency
-        if (!(cs_on && cs_img == J)) {
+        if constexpr ((VAR & 2) != 0) {
+            __builtin_amdgcn_sched_group_barrier(0x100, J == 2 ? 24 : 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        } else if (!(cs_on && cs_img == J)) {
 #pragma unroll
             for (int k = 0; k < (J == 2 ? 12 : 8); ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -228,10 +268,14 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
             __builtin_amdgcn_sched_group_barrier(0x008, J == 2 ? 4 : 8, 0);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this segment's reads are retired before its closing barrier (WAR)
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+        DW8_STAMP(s4);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef GV_DW8_STAMPS
+        { DW8_STAMP(s5); c_is += s2 - s1; c_b1 += s3 - s2; c_mf += s4 - s3; c_b2 += s5 - s4; }
+#endif
     };
     int t = 0;
     for (; t + 1 < nt; t += 2) {
@@ -239,8 +283,14 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
         phase(I0{}, I1{}, I1{}, I1{}, t + 1); phase(I1{}, I1{}, I1{}, I0{}, t + 1); phase(I2{}, I1{}, I1{}, I1{}, t + 1);
     }
     if (t < nt) { phase(I0{}, I0{}, I0{}, I0{}, t); phase(I1{}, I0{}, I0{}, I1{}, t); phase(I2{}, I0{}, I0{}, I0{}, t); }
-    if (wm == 0) __builtin_amdgcn_s_barrier();       // pair the late half's last barrier
+    if (wm == 0 && !(VAR & 4)) __builtin_amdgcn_s_barrier();       // pair the late half's last barrier
     wait_vmcnt<0>();                                  // the dummy tiles' DMA must not outlive the workgroup
+#ifdef GV_DW8_STAMPS
+    if (g.dbg && lane == 0) {
+        unsigned long long* o = g.dbg + ((long)blockIdx.x * 8 + wave) * 8;
+        o[0] = c_rd; o[1] = c_is; o[2] = c_b1; o[3] = c_mf; o[4] = c_b2; o[5] = dw8_stamp() - t_start; o[6] = nt;
+    }
+#endif
 
     // ---- partial tile -> slab (row-major like C; 64-B segments per 4 lanes, neighbouring fragments complete the lines)
     if constexpr (!SWAP) {
@@ -252,6 +302,7 @@ __device__ __forceinline__ void dw8_body(const Dw8P& g, const int slice, const i
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int m = p0 + wm * 64 + i * 16 + li16, n = q0 + b * 128 + (2 * wn + j) * 16 + gq * 4;
+                    if constexpr ((VAR & 32) != 0) asm volatile("" ::"v"(acc[b][i][j])); else
                     *(f32x4*)(sl + (long)m * g.Qn + n) = acc[b][i][j];
                 }
         if (cs_on && gq == 0) atomicAdd(g.colsum + p0 + wm * 64 + wn * 16 + li16, csum[0][0]);
@@ -280,12 +331,12 @@ __device__ __forceinline__ int dw8_item() {
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + lw;
 }
 
-template <bool SWAP>
+template <bool SWAP, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void dw8_kernel(const Dw8P g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int item = dw8_item(), tiles = g.tiles_p * g.tiles_q;
     const int slice = item / tiles;
-    dw8_body<SWAP>(g, slice, item - slice * tiles, (GV_LDS char*)smem_raw);
+    dw8_body<SWAP, VAR>(g, slice, item - slice * tiles, (GV_LDS char*)smem_raw);
 }
 
 // the weight-gradient products of one transformer block (all reduce over the same token rows) as ONE launch: items are
@@ -300,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void dw8_group_kernel(const Dw8GroupP G) {
     int q = 0;
 #pragma unroll
     for (int i = 1; i < GV_DW_GROUP_MAX; ++i) q += (i < G.n && tg >= G.tile_base[i]) ? 1 : 0;
-    dw8_body<false>(G.prob[q], slice, tg - G.tile_base[q], (GV_LDS char*)smem_raw);
+    dw8_body<false, 0>(G.prob[q], slice, tg - G.tile_base[q], (GV_LDS char*)smem_raw);
 }
 
 }  // namespace gvgemm

@@ -86,8 +86,23 @@ struct PanelP {
     const float* row_scale; const float* gb_scale;
     // wide (plain Linear with N = ncb x 384 output columns, bf16 out): out = epilogue(A W^T) one 384-column block after the other
     bf16* outb; long ldob; const bf16* aux_in; bf16* aux_out; long ld_aux; int ncb, n_total;
+#ifdef GV_PANEL_STAMPS          // lab: s_memtime stamps [workgroup][wave][panel][8]
+    unsigned long long* dbg;
+#endif
 };
 
+#ifdef GV_PANEL_STAMPS
+__device__ __forceinline__ unsigned long long panel_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PSTAMP(k) do { if (lane == 0 && blockIdx.x < 256 && it < 8) p.dbg[((blockIdx.x * 8 + wave) * 8 + it) * 8 + (k)] = panel_stamp(); } while (0)
+#else
+#define PSTAMP(k)
+#endif
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_WIDE = 2 };
 // MODE_WIDE epilogues (the GV_EPI_* combinations of the hot path's wide products)
@@ -225,6 +240,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         for (int e = 0; e < 2; ++e) { s_dg[c][e] = 0.f; s_db[c][e] = 0.f; s_g[c][e] = 0.f; }
     for (int it = 0; it < nit; ++it) {
     int m0_next = m0;
+    PSTAMP(0);
     if constexpr (PP) {
         const bool has_next = MODE == MODE_WIDE && it + 1 < nit;
         uc_past = has_next ? 0 : nt - 1;
@@ -239,6 +255,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         // prologue: tile 0 is out (start of the kernel / before the previous block's epilogue); A, W0, W1 of tile 1 follow
         static_for<0, PA + 4>([&](auto X) { issue_x(X, 1, 1, baseA); });
         wait_vmcnt<PN_T + 2>();                               // A and W0 of tile 0 landed
+        PSTAMP(1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();            // the second half runs one barrier late
@@ -312,6 +329,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         // WIDE: the image lives in stage 1 and behind it and the pieces in flight are the NEXT panel's tile 0 into stage 0 --
         // they keep flying through the epilogue (the kernel's end waits for the last ones)
         if constexpr (MODE != MODE_WIDE) wait_vmcnt<0>();
+        PSTAMP(2);
     }
     if constexpr (!PP) {
 #pragma unroll
@@ -346,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     // and works on units of 4 rows x 32 columns (lane: row 4 q + (lane >> 4), columns 2 (lane & 15) + {0, 1}): every global access
     // of a unit is four 64-B row pieces (128-B for the f32 output), which the neighbouring wave (wn + 1) completes to full lines.
     // Round 2 ran the wide epilogues on the LayerNorm kernels' scheme -- a workgroup-wide image, one wave per 768-B row, two
-    // barriers per 32 rows: 8 us per 176 x 384 panel with NO global store in it (a lab build without stores), as long as
+    // barriers per 32 rows: 8 us per 176 x 384 panel with NO global store in it (tools/lab.sh GV_LAB_WIDE_NOSTORE), as long as
     // the panel's k-loop.  Nothing here needs a whole row in one wave, so nothing needs the other waves.
     if constexpr (MODE == MODE_WIDE) {
         constexpr int RS = 100;
@@ -364,9 +382,15 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 bw[b][j] = (WB && p.bias) ? *(const f32x4*)(p.bias + cb * PN + 128 * b + 16 * (2 * wn + j) + gqe * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        PSTAMP(3);
         __syncthreads();                                          // every wave is past ring stage 1: it is image space now
+        PSTAMP(4);
         static_for<0, FMH>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
+#ifdef GV_LAB_WIDE_NOEPI        // lab: the k-loops alone (one accumulator value keeps them alive)
+            if (acc8[0][i][0][0] == 1.2345e38f) p.outb[0] = (bf16)1.0f;
+            if (true) return;
+#endif
             if (i < nfr) {                                        // (wave-uniform; static but for a half's last fragment)
                 const int mrow = m0 + 16 * (f0 + i) + urow;       // + 4 q: this lane's row of unit (b, q); < M (every panel holds BM rows)
                 const int ccol = cb * PN + 32 * wn + ucol;        // + 128 b
@@ -408,6 +432,12 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                     for (int q = 0; q < 4; ++q) {
                         const f32x2 t2 = *(GV_LDS f32x2*)(wimg + (4 * q + urow) * RS + 32 * b + ucol);       // (a wave's LDS accesses execute in order)
                         float v0 = t2[0], v1 = t2[1];
+#ifdef GV_LAB_WIDE_NOSTORE      // lab: image transit + epilogue arithmetic, no global stores
+                        if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v0 = gelu_f(v0); v1 = gelu_f(v1); }
+                        if constexpr (EP == EP_DGELU) { v0 *= dgelu_f((float)ax[b * 4 + q][0]); v1 *= dgelu_f((float)ax[b * 4 + q][1]); }
+                        if (v0 + v1 == 1.2345e38f) p.outb[0] = (bf16)v0;
+                        if (true) continue;
+#endif
                         if constexpr (EP == EP_BIAS_RESID) {
                             *(f32x2*)(o_f32 + q * s_of + 128 * b) = f32x2{fmaf(v0, rsc[q], ar[b * 4 + q][0]), fmaf(v1, rsc[q], ar[b * 4 + q][1])};
                         } else {
@@ -420,12 +450,18 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                             if constexpr (EP == EP_BIAS_GELU || EP == EP_BIAS_GELU_SAVE) { v0 = gelu_f(v0); v1 = gelu_f(v1); }
                             if constexpr (EP == EP_DGELU) { v0 *= dgelu_f((float)ax[b * 4 + q][0]); v1 *= dgelu_f((float)ax[b * 4 + q][1]); }
                             bf16x2* dst = (bf16x2*)(o_bf + q * s_ob + 128 * b);
+#ifdef GV_LAB_WIDE_NT
+                            __builtin_nontemporal_store(bf16x2{(bf16)v0, (bf16)v1}, dst);
+#else
                             *dst = bf16x2{(bf16)v0, (bf16)v1};
+#endif
                         }
                     }
             }
         });
+        PSTAMP(5);
         __syncthreads();                                          // images are read: stage 1 may receive the next panel's tile 1
+        PSTAMP(6);
     }
     // ---- epilogue (FWD / BWD).  The accumulators pass through an LDS image so that the row phase works on whole rows, ONE WAVE PER
     // ROW (wave w: rows w, w + 8, .. of the pass): every global access is a full 512-B row segment and the row reductions
@@ -477,9 +513,21 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         return 16 * (h * FMH + i0 + ii) + 8 * (rr & 1);
     };
     if constexpr (MODE != MODE_WIDE) {
-    // The row phase is HBM-bound (s_memtime stamps of a lab build: forward 170 MB, backward 237 MB per launch at 5.6 - 5.9 TB/s, as long
-    // as the k-loop).  Requesting pass p + 1's rows ahead of pass p's stores was measured and changes nothing (LAB_NOTES.md).
+    PSTAMP(3);
+    // The row phase is HBM-bound (s_memtime stamps, tools/panel_stamps.py: forward 170 MB, backward 237 MB per launch at 5.6 - 5.9
+    // TB/s, as long as the k-loop).  Lab switch GV_LAB_EPI_PIPELINE requests the rows of pass p + 1 right behind pass p's image
+    // barrier -- ahead of pass p's stores, into a second register set -- on the theory that a wave's memory operations retire in
+    // order and read bursts therefore wait for write bursts: measured on one box against this ordering (tools/panel_bench.py,
+    // round 3), forward 44.6 - 47.7 vs 45.9 - 47.7 us (K = 384), 88 - 92 vs 89 - 90 (K = 1536), backward 59 vs 54 (K = 384), 95 vs
+    // 94 - 98 (K = 1536): nothing, and the variants that start at pass 0 spill 44 - 92 B per lane and lose 10 %.  Not a burst effect.
     constexpr int PSTEP = PP ? IBH : IB, NPASS = ((PP ? FMH : FM) + PSTEP - 1) / PSTEP;
+    // first pass that requests its successor's rows early: the largest panels have no registers for it while most accumulators
+    // are still live (forward: from pass 1 of 3; backward: from pass 2 of 6 -- earlier spills 44 - 92 B per lane)
+#ifndef GV_EPI_PIPE0_FWD
+#define GV_EPI_PIPE0_FWD 1
+#define GV_EPI_PIPE0_BWD 2
+#endif
+    constexpr int EPI_PIPE0 = FM >= 9 ? (MODE == MODE_FWD ? GV_EPI_PIPE0_FWD : GV_EPI_PIPE0_BWD) : 0;
     f32x2 pre_a[2][RPW][3], pre_b[2][MODE == MODE_BWD ? RPW : 1][3];
     float pre_mean[2][MODE == MODE_BWD ? RPW : 1], pre_rstd[2][MODE == MODE_BWD ? RPW : 1];
     auto prefetch = [&](auto Pc) {
@@ -496,7 +544,11 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
                     if constexpr (MODE == MODE_FWD) {
                         pre_a[S][rr][c] = p.resid ? *(const f32x2*)(p.resid + (long)m * p.ldr + col) : f32x2{0.f, 0.f};
                     } else {
+#ifdef GV_NT_X          // lab: the LayerNorm input row is read here for the last time in the step
+                        pre_a[S][rr][c] = __builtin_nontemporal_load((const f32x2*)(p.x + (long)m * p.ldx + col));
+#else
                         pre_a[S][rr][c] = *(const f32x2*)(p.x + (long)m * p.ldx + col);
+#endif
                         pre_b[S][rr][c] = p.g_init ? f32x2{0.f, 0.f} : *(const f32x2*)(p.g + (long)m * p.ldg + col);
                     }
                 }
@@ -508,7 +560,11 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     static_for<0, NPASS>([&](auto Pc) {
         constexpr int ps = decltype(Pc)::value, i0 = ps * PSTEP, S = ps & 1;
         constexpr int ni = ((PP ? FMH : FM) - i0) < PSTEP ? ((PP ? FMH : FM) - i0) : PSTEP;
+#ifdef GV_LAB_EPI_PIPELINE
+        if constexpr (ps >= 1 && ps - 1 < EPI_PIPE0) prefetch(Pc);       // not requested early (see below)
+#else
         if constexpr (ps >= 1) prefetch(Pc);
+#endif
         if constexpr (i0 == 0) __syncthreads();                   // every wave is past the ring: it is image space now
         // ---- accumulators -> LDS image [rows of this pass][384 columns] f32
         if constexpr (PP) {
@@ -541,7 +597,11 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         __syncthreads();
         // (pass 0 still holds most of the accumulators: its successor's rows are requested at the top of pass 1, as before --
         //  requesting them here overflows the register file by ~20 registers at FM = 11 / 12)
+#ifdef GV_LAB_EPI_PIPELINE
+        if constexpr (ps + 1 < NPASS && ps >= EPI_PIPE0) prefetch(std::integral_constant<int, ps + 1>{});     // ahead of this pass's stores
+#else
         if constexpr (false) {}
+#endif
 
         // ---- one wave per row
 #pragma unroll
@@ -562,7 +622,11 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             v[c][0] = fmaf(v[c][0], rs, pre_a[S][rr][c][0]); v[c][1] = fmaf(v[c][1], rs, pre_a[S][rr][c][1]);
+#ifdef GV_NT_XOUT     // lab: the f32 residual row is read again two kernels later (epilogue, prefetched) -- leave the cache to h / qkv
+                            __builtin_nontemporal_store(f32x2{v[c][0], v[c][1]}, (f32x2*)(orow + (c * 64 + lane) * 2));
+#else
                             *(f32x2*)(orow + (c * 64 + lane) * 2) = f32x2{v[c][0], v[c][1]};
+#endif
                         }
                         if (ln) {
                             float sm = 0.f;
@@ -577,7 +641,11 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
                             for (int c = 0; c < 3; ++c) {
                                 const bf16x2 yv = bf16x2{(bf16)((v[c][0] - mean) * rstd * gm[c][0] + bt[c][0]), (bf16)((v[c][1] - mean) * rstd * gm[c][1] + bt[c][1])};
+#ifdef GV_NT_Y
+                                __builtin_nontemporal_store(yv, (bf16x2*)(yrow + (c * 64 + lane) * 2));
+#else
                                 *(bf16x2*)(yrow + (c * 64 + lane) * 2) = yv;
+#endif
                             }
                             if (lane == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
                         }
@@ -624,6 +692,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
         __syncthreads();                                          // image free for the next pass / the reduction below
     });
     }
+    if constexpr (MODE != MODE_WIDE) { PSTAMP(6); }
     if constexpr (MODE == MODE_WIDE) {                            // next row panel (its tile 0 went out as tile nt of this panel's stream)
         m0 = m0_next; baseA = baseA_past;
     }
@@ -664,6 +733,9 @@ int pick_fm(int M) {
     return 12;
 }
 
+#ifdef GV_PANEL_STAMPS
+unsigned long long* g_panel_dbg = nullptr;
+#endif
 // MODE_WIDE launch geometry (see the kernel's id mapping): groups of ncb sibling workgroups, ceil(groups / 8) per XCD
 int wide_grid(int M, int BM, int ncb) {
     const int P = (M + BM - 1) / BM, groups = (P + ncb - 1) / ncb;
@@ -690,6 +762,11 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
     static const Name kn;                                           // as rocprofv3 prints it (initialised once, thread-safe)
     const char* kname = kn.s;
     const int grid = MODE == MODE_WIDE ? wide_grid(p.M, C::BM, p.ncb) : (p.M + C::BM - 1) / C::BM;
+#ifdef GV_PANEL_STAMPS
+    if (!g_panel_dbg) { (void)hipMalloc(&g_panel_dbg, 256 * 8 * 8 * 8 * 8); }
+    (void)hipMemsetAsync(g_panel_dbg, 0, 256 * 8 * 8 * 8 * 8, s);
+    const_cast<PanelP&>(p).dbg = g_panel_dbg;
+#endif
     // algorithmic bytes: forward  A row + f32 residual in + f32 row out + bf16 normalised row out + stats;
     // backward  dY row + f32 x row + f32 g in / out + bf16 g out; + the weight once
     // wide: A row + the bf16 output row (+ the saved / re-read pre-activation row)
@@ -732,6 +809,9 @@ int dispatch_fm(const PanelP& p, hipStream_t s, const char* name) {
 // the hot path's epilogues, on the full-row kernel -- row panels sized for ONE round of workgroups, 768-B row segments out.
 // Returns -1 when the call is not one of these (the caller then runs the 128x128-tile kernel).
 int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
+#ifdef GV_LAB_WIDE2      // lab build with tools/lab/panel2.hip linked in: the two-context form of these products (measured, slower: LAB_NOTES.md)
+    { extern int gv_panel_wide2(const gv_linear_args*, hipStream_t); const int rc2 = gv_panel_wide2(a, s); if (rc2 != -1) return rc2; }
+#endif
     if (a->trans_a || a->N % PN != 0 || a->K % 128 != 0 || a->M < 2048 || a->ldc % 2 != 0) return -1;
     if (a->alpha != 0.f && a->alpha != 1.f) return -1;
     const bool plan = s == (hipStream_t)(intptr_t)-1;       // gv_workspace_bytes: "would this call run here?" (these kernels take no scratch)
@@ -766,6 +846,9 @@ int gv_panel_wide(const gv_linear_args* a, hipStream_t s) {
     return -1;
 }
 
+#ifdef GV_PANEL_STAMPS   // tuning-lab build only (tools/panel_stamps.py)
+extern "C" int gv_panel_dbg_read(unsigned long long* host) { if (!g_panel_dbg) return -1; return (int)hipMemcpy(host, g_panel_dbg, 256 * 8 * 8 * 8 * 8, hipMemcpyDeviceToHost); }
+#endif
 
 extern "C" int gv_linear_ln_blocks(int32_t M) {
     if (M <= 0) return 0;

@@ -233,7 +233,7 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=dev)         # RCCL
         reducer = RcclReducer()
         if primary:
-            _logger.info("data parallel over %d ranks (RCCL): %d CUs left to communication, launches sized for %d", world, comm["comm_cus"], comm["cu_budget"])
+            _logger.info("data parallel over %d ranks (RCCL): launches sized for %d CUs (GIPVIT_COMM_CUS=%d)", world, comm["cu_budget"], comm["comm_cus"])
     torch.manual_seed(args.seed + rank)                        # utils.random_seed(seed, rank), train.py:467
 
     ignored = [e["flags"][-1] for e in REFERENCE_FLAGS if not e["used"] and e["flags"][-1].startswith("-")
