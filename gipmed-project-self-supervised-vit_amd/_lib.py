@@ -67,6 +67,10 @@ gv_linear_args = _struct("gv_linear_args", [
 gv_linear_ln_fwd_args = _struct("gv_linear_ln_fwd_args", [
     ("A", vp), ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldw", i64), ("bias", vp), ("resid", vp), ("ldr", i64),
     ("out", vp), ("ldo", i64), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp), ("mean", vp), ("rstd", vp), ("row_scale", vp)])
+gv_mlp_ln_fwd_args = _struct("gv_mlp_ln_fwd_args", [
+    ("A", vp), ("W1", vp), ("bias1", vp), ("W2", vp), ("bias2", vp), ("M", i32), ("N", i32), ("K", i32), ("hidden", i32),
+    ("lda", i64), ("ldw1", i64), ("ldw2", i64), ("resid", vp), ("ldr", i64), ("out", vp), ("ldo", i64),
+    ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp), ("mean", vp), ("rstd", vp), ("row_scale", vp)])
 gv_linear_ln_bwd_args = _struct("gv_linear_ln_bwd_args", [
     ("A", vp), ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i64), ("ldw", i64), ("x", vp), ("ldx", i64),
     ("mean", vp), ("rstd", vp), ("gamma", vp), ("g", vp), ("ldg", i64), ("gb", vp), ("ldgb", i64), ("partials", vp),
@@ -133,7 +137,7 @@ gv_lamb_args = _struct("gv_lamb_args", [
 ENTRY_POINTS = {
     "gv_patchify": gv_patchify_args, "gv_crop_resize": gv_crop_resize_args, "gv_crop_augment": gv_crop_augment_args, "gv_augment": gv_augment_args, "gv_layernorm_fwd": gv_layernorm_fwd_args, "gv_layernorm_bwd": gv_layernorm_bwd_args,
     "gv_colsum_finalize": gv_colsum_finalize_args, "gv_ln_finalize": gv_ln_finalize_args, "gv_colsum": gv_colsum_args, "gv_linear": gv_linear_args,
-    "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args, "gv_expand_rows": gv_expand_rows_args, "gv_linear_dw_group": gv_linear_dw_group_args,
+    "gv_linear_ln_fwd": gv_linear_ln_fwd_args, "gv_mlp_ln_fwd": gv_mlp_ln_fwd_args, "gv_linear_ln_bwd": gv_linear_ln_bwd_args, "gv_expand_rows": gv_expand_rows_args, "gv_linear_dw_group": gv_linear_dw_group_args,
     "gv_attention_fwd": gv_attention_fwd_args, "gv_attention_fwd_varlen": gv_attention_fwd_varlen_args, "gv_attention_bwd": gv_attention_bwd_args, "gv_attention_bwd_varlen": gv_attention_bwd_varlen_args, "gv_cls_rows": gv_cls_rows_args,
     "gv_tokens_bwd": gv_tokens_bwd_args, "gv_small_matmul": gv_small_matmul_args, "gv_l2norm_fwd": gv_l2norm_fwd_args,
     "gv_l2norm_bwd": gv_l2norm_bwd_args, "gv_weightnorm_fwd": gv_weightnorm_fwd_args, "gv_weightnorm_bwd": gv_weightnorm_bwd_args,

@@ -86,6 +86,8 @@ struct PanelP {
     const float* row_scale; const float* gb_scale;
     // wide (plain Linear with N = ncb x 384 output columns, bf16 out): out = epilogue(A W^T) one 384-column block after the other
     bf16* outb; long ldob; const bf16* aux_in; bf16* aux_out; long ld_aux; int ncb, n_total;
+    // fused MLP (forward, EP = EP_MLP): A -> fc1 (W, bias1, `hidden` columns) -> GELU -> fc2 (W2, bias) -> the forward epilogue
+    const bf16* W2; long ldw2; const float* bias1; int hidden;
 };
 
 
@@ -94,6 +96,7 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_WIDE = 2 };
 // EP_BIAS_RESID: f32 output = (A W^T + bias) * row_scale + resid -- x + proj(a) / x + fc2(h) of the widths that have no fused
 // LayerNorm kernel (ViT-B: N = 768)
 enum { EP_NONE = 0, EP_BIAS = 1, EP_BIAS_GELU = 2, EP_BIAS_GELU_SAVE = 3, EP_DGELU = 4, EP_BIAS_RESID = 5 };
+constexpr int EP_MLP = 1;           // (MODE_FWD only: the fused-MLP variant of the forward kernel)
 
 // PP = 1: the k-loop of gemm_dw8.h (ping-pong halves, three phases per 64-deep K-tile, counted LDS-DMA stream) instead of the
 // one-stage-ahead loop: waves (wm, wn) = (wave >> 2, wave & 3); the wm = 0 half owns the first FMH = ceil(FM / 2) row fragments,
@@ -103,6 +106,10 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     using C = PC<FM, NW, BK>;
     constexpr int NF = C::NF;
     static_assert(!PP || (NW == 8 && BK == 64), "ping-pong loop: 8 waves, BK = 64");
+    // MODE_FWD with EP = EP_MLP: mlp.fc1 -> GELU -> mlp.fc2 in ONE kernel (vit.pyc@L98-104) in front of the forward epilogue
+    // (+ bias + residual + the next LayerNorm): the hidden activation never exists in HBM.  See the k-loop below.
+    constexpr bool MLP = MODE == MODE_FWD && EP == EP_MLP;
+    static_assert(!MLP || (!PP && NW == 8 && BK == 64 && !TB && C::A_BYTES <= C::W_BLOCK), "fused MLP: one-stage-ahead loop, 8 waves, natural weights, <= 128 rows");
     constexpr int FMH = (FM + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GV_LDS char* smem = (GV_LDS char*)smem_raw;
@@ -149,12 +156,32 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
     TileSrc<false, C::A_ROWS, BK, NW> srcA;
     TileSrc<TB, 128, BK, NW> srcW[3];
     const int n_total = MODE == MODE_WIDE ? p.n_total : PN;
+    TileSrc<false, 128, BK, NW> srcW2[MLP ? 3 : 1];
     if constexpr (!PP) {
         srcA.setup(p.A, p.lda, m0, M, wave, lane);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, n_total, wave, lane);
+        for (int j = 0; j < 3; ++j) srcW[j].setup(p.W, p.ldw, 128 * j, MLP ? p.hidden : n_total, wave, lane);
+        if constexpr (MLP) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) srcW2[j].setup(p.W2, p.ldw2, 128 * j, PN, wave, lane);
+        }
     }
     const int nt = p.K / BK;
+    // ---- fused MLP: ring slots of 3 weight blocks (48 KB).  A fc1 stage = the A tile + 2 blocks of W1 (256 hidden columns x 64 k),
+    // a fc2 stage = 3 blocks of W2 (384 output columns x 64 hidden columns); behind the two slots, the chunk's hidden activation
+    // H [A_ROWS][256] bf16 as four 64-deep tiles in the A operand's LDS format
+    constexpr int HC = 256, MSLOT = 3 * C::W_BLOCK, HT = C::A_ROWS * BK * 2;
+    auto mlp_issue1 = [&](int c, int r, int slot) {             // fc1 stage r of chunk c
+        GV_LDS char* st = smem + slot * MSLOT;
+        srcA.issue(p.lda, r * BK, p.K, st, wave);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) srcW[j].issue(p.ldw, c * HC * (int)p.ldw + r * BK, p.K, st + C::A_BYTES + j * C::W_BLOCK, wave);
+    };
+    auto mlp_issue2 = [&](int c, int kt, int slot) {            // fc2 stage kt of chunk c
+        GV_LDS char* st = smem + slot * MSLOT;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) srcW2[j].issue(p.ldw2, c * HC + kt * BK, p.hidden, st + j * C::W_BLOCK, wave);
+    };
     // PP: LDS-DMA sources as uniform base (SGPRs) + per-lane 32-bit byte offset, as in gemm_dw8.h.  A image piece pc: rows
     // (wave a + pc) 8 .. + 7 (clamped at M), 128 B each, 16-B chunk XOR (row & 7); W block piece pc: natural -- weight rows
     // (wave 2 + pc) 8 .. + 7 of the block; transposed -- reduction rows (wave 2 + pc) 4 .. + 3, 256 B of the block's columns each
@@ -216,8 +243,9 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
             else glds16_s<b * 256>(baseW + (unsigned long long)uc * BK * p.ldw * 2, voffW[pc], dst);
         }
     };
-    if constexpr (PP) static_for<0, PN_T>([&](auto X) { issue_x(X, 0, 0, baseA); }); else
-    issue(0);
+    if constexpr (PP) static_for<0, PN_T>([&](auto X) { issue_x(X, 0, 0, baseA); });
+    else if constexpr (MLP) mlp_issue1(0, 0, 0);
+    else issue(0);
     float s_dg[3][2], s_db[3][2], s_g[3][2];          // backward: column sums over this workgroup's rows
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -319,7 +347,72 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (!PP) for (int t = 0; t < nt; ++t) {
+    if constexpr (MLP) {
+        // Per chunk c of 256 hidden columns: fc1 over K (nt stages; wave w owns the chunk's column fragments {w, w + 8}) -> + bias1,
+        // GELU, bf16 -> H in LDS -> fc2 over the chunk (4 stages; wave w owns output fragments {w, w + 8, w + 16} as in the plain
+        // loop, A fragments from H).  One accumulator chain per output over the hidden index in increasing order: bit-identical to
+        // gv_linear (BIAS | GELU) followed by gv_linear_ln_fwd.  The DMA stream runs one stage ahead across both products.
+        GV_LDS char* Himg = smem + 2 * MSLOT;
+        const int nchunk = p.hidden / HC;
+        int slot = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            f32x4 acc1[FM][2], b1v[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b1v[j] = *(const f32x4*)(p.bias1 + c * HC + 16 * (NW * j + wave) + gq * 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < nt; ++r, slot ^= 1) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (r + 1 < nt) mlp_issue1(c, r + 1, slot ^ 1); else mlp_issue2(c, 0, slot ^ 1);
+                GV_LDS char* cur = smem + slot * MSLOT;
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    bf16x8 fw[2], fa[FM];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fw[j] = read_frag<false, 128, BK>(cur + C::A_BYTES + j * C::W_BLOCK, wave, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) fa[i] = read_frag<false, C::A_ROWS, BK>(cur, i, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc1[i][j] = GV_MFMA_16x16x32(fw[j], fa[i], acc1[i][j]);
+                }
+            }
+            // hidden column 16 (8 j + wave) + 4 gq + r of the chunk = k index of fc2: tile 2 j + (wave >> 2), 16-B chunk 2 (wave & 3) + (gq >> 1)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 v = acc1[i][j] + b1v[j];
+                    const int row = 16 * i + li16;
+                    *(GV_LDS bf16x4*)(Himg + (2 * j + (wave >> 2)) * HT + row * (BK * 2) + (((2 * (wave & 3) + (gq >> 1)) ^ swz_n<BK>(row)) << 4) + (gq & 1) * 8) =
+                        bf16x4{(bf16)gelu_f(v[0]), (bf16)gelu_f(v[1]), (bf16)gelu_f(v[2]), (bf16)gelu_f(v[3])};
+                }
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // H is written before the next barrier lets anybody read it
+            for (int kt = 0; kt < HC / BK; ++kt, slot ^= 1) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < HC / BK) mlp_issue2(c, kt + 1, slot ^ 1); else if (c + 1 < nchunk) mlp_issue1(c + 1, 0, slot ^ 1);
+                GV_LDS char* cur = smem + slot * MSLOT;
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    bf16x8 fw[NF], fa[FM];
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) fw[j] = read_frag<false, 128, BK>(cur + j * C::W_BLOCK, wave, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) fa[i] = read_frag<false, C::A_ROWS, BK>(Himg + kt * HT, i, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j) acc[i][j] = GV_MFMA_16x16x32(fw[j], fa[i], acc[i][j]);
+                }
+            }
+        }
+    }
+    if constexpr (!PP && !MLP) for (int t = 0; t < nt; ++t) {
         wait_vmcnt<0>();                      // my pieces of stage t have landed (nothing younger is in flight yet)
         __builtin_amdgcn_s_barrier();         // everybody's have; every wave is past its reads of stage t - 1
         if (t + 1 < nt) issue(t + 1);
@@ -656,7 +749,9 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 // rows per workgroup for M rows: the smallest supported FM that covers M in as few full rounds of 256 workgroups as possible
 constexpr int FM_SET8[] = {4, 7, 9, 11, 12};
 int cu_budget() { return gv_cu_budget(); }       // 256, or 256 - C under a data-parallel run that leaves C CUs to RCCL (gv_common.h)
+int fm_floor() { static const int f = [] { const char* e = getenv("GIPVIT_FM_FLOOR"); return e ? atoi(e) : 0; }(); return f; }
 int pick_fm(int M) {
+    if (fm_floor() >= 11 && M >= 8192) return fm_floor() >= 12 ? 12 : 11;
     const int m16 = (M + 15) / 16;
     const int rounds = (m16 + cu_budget() * 12 - 1) / (cu_budget() * 12);
     const int need = (m16 + cu_budget() * rounds - 1) / (cu_budget() * rounds);
@@ -672,6 +767,7 @@ int wide_grid(int M, int BM, int ncb) {
 // ... and the smallest supported FM whose WORKING workgroups (ncb per group of panels; the grid's padding to 8 ncb exits at once)
 // fit one round of the CU budget; 12 (several rounds) for larger M
 int pick_fm_wide(int M, int ncb) {
+    if (fm_floor() >= 11 && M >= 8192) return fm_floor() >= 12 ? 12 : 11;
     for (int fm : FM_SET8) {
         const int P = (M + 16 * fm - 1) / (16 * fm), groups = (P + ncb - 1) / ncb;
         if (groups * ncb <= cu_budget() && wide_grid(M, 16 * fm, ncb) <= 256) return fm;
@@ -683,7 +779,10 @@ template <int FM, int NW, int BK, bool TB, int MODE, int EP = 0, int PP = 0>
 int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
     auto kern = panel_kernel<FM, NW, BK, TB, MODE, EP, PP>;
     using C = PC<FM, NW, BK>;
-    constexpr int LDS_BYTES = MODE == MODE_WIDE ? C::LDS_WIDE : C::LDS;
+    constexpr bool MLP = MODE == MODE_FWD && EP == EP_MLP;
+    constexpr int LDS_MLP = 2 * 3 * C::W_BLOCK + 4 * C::A_ROWS * BK * 2;      // two ring slots + the chunk's hidden activation
+    static_assert(!MLP || (LDS_MLP <= 160 * 1024 && LDS_MLP >= C::LDS - 2 * C::A_BYTES), "fused MLP: LDS");
+    constexpr int LDS_BYTES = MLP ? LDS_MLP : (MODE == MODE_WIDE ? C::LDS_WIDE : C::LDS);
     static GvLdsOptIn opt_in;
     if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, LDS_BYTES, name)) return rc;
     struct Name { char s[96]; Name() { snprintf(s, sizeof(s), "panel_kernel<%d, %d, %d, %s, %d, %d, %d>", FM, NW, BK, TB ? "true" : "false", MODE, EP, PP); } };
@@ -696,7 +795,9 @@ int launch_panel(const PanelP& p, hipStream_t s, const char* name) {
     const int nout = MODE == MODE_WIDE ? p.n_total : PN;
     const double row_bytes = MODE == MODE_WIDE ? 2.0 * p.K + (EP == EP_BIAS_RESID ? 8.0 * nout : 2.0 * nout * ((EP == EP_BIAS_GELU_SAVE || EP == EP_DGELU) ? 2 : 1))
                              : MODE == MODE_FWD ? 2.0 * p.K + PN * 4 * 2 + PN * 2 + 8 : 2.0 * p.K + PN * 4 * 3 + PN * 2 + 8;
-    const int th = gvtime::enabled() ? gvtime::begin(kname, 2.0 * p.M * nout * p.K, p.M * row_bytes + 2.0 * nout * p.K, s) : -1;
+    const double flops = MLP ? 4.0 * p.M * p.hidden * p.K : 2.0 * p.M * nout * p.K;
+    const double bytes = p.M * row_bytes + (MLP ? 4.0 * p.hidden * p.K : 2.0 * nout * p.K);
+    const int th = gvtime::enabled() ? gvtime::begin(kname, flops, bytes, s) : -1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS_BYTES, s, p);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK(name);
@@ -787,6 +888,31 @@ extern "C" int gv_linear_ln_fwd(const gv_linear_ln_fwd_args* a, void* stream) {
     p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps; p.y = (bf16*)a->y; p.mean = a->mean; p.rstd = a->rstd;
     p.row_scale = a->row_scale;
     return dispatch_fm<false, MODE_FWD>(p, (hipStream_t)stream, "gv_linear_ln_fwd");
+}
+
+// mlp.fc1 -> GELU -> mlp.fc2 -> + residual -> the next LayerNorm in ONE launch (vit.pyc@L98-104, L146-152) for passes that keep no
+// activations (the DINO teacher, inference): the [M, hidden] activation never exists in HBM.  112-row panels (64 for short M).
+extern "C" int gv_mlp_ln_fwd(const gv_mlp_ln_fwd_args* a, void* stream) {
+    GV_REQUIRE(a && a->A && a->W1 && a->W2 && a->bias1 && a->out, GV_E_NULL, "gv_mlp_ln_fwd: null operand");
+    GV_REQUIRE(a->N == PN, GV_E_UNSUPPORTED, "gv_mlp_ln_fwd: built for N = %d output columns (ViT-S), got %d", PN, a->N);
+    GV_REQUIRE(a->M > 0 && a->K > 0 && a->K % 64 == 0 && a->hidden > 0 && a->hidden % 256 == 0, GV_E_SHAPE,
+               "gv_mlp_ln_fwd: need M > 0, K %% 64 == 0, hidden %% 256 == 0 (got M=%d K=%d hidden=%d)", a->M, a->K, a->hidden);
+    GV_REQUIRE((long)a->hidden * a->ldw1 < (1L << 31), GV_E_SHAPE, "gv_mlp_ln_fwd: fc1 weight too large for 32-bit element offsets");
+    GV_REQUIRE(a->lda % 8 == 0 && a->ldw1 % 8 == 0 && a->ldw2 % 8 == 0 && a->ldo % 2 == 0 && a->ldr % 4 == 0, GV_E_ALIGN, "gv_mlp_ln_fwd: leading dimensions misaligned");
+    GV_REQUIRE(gv_aligned(a->A, 16) && gv_aligned(a->W1, 16) && gv_aligned(a->W2, 16) && gv_aligned(a->out, 16) && gv_aligned(a->bias1, 16), GV_E_ALIGN,
+               "gv_mlp_ln_fwd: A / W1 / W2 / out / bias1 must be 16-byte aligned");
+    if (a->bias2) GV_REQUIRE(gv_aligned(a->bias2, 16), GV_E_ALIGN, "gv_mlp_ln_fwd: bias2 misaligned");
+    if (a->resid) GV_REQUIRE(gv_aligned(a->resid, 16), GV_E_ALIGN, "gv_mlp_ln_fwd: resid misaligned");
+    if (a->gamma) GV_REQUIRE(a->beta && a->y && a->mean && a->rstd, GV_E_NULL, "gv_mlp_ln_fwd: gamma given, so beta / y / mean / rstd are required");
+    PanelP p{};
+    p.A = (const bf16*)a->A; p.W = (const bf16*)a->W1; p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw1;
+    p.W2 = (const bf16*)a->W2; p.ldw2 = a->ldw2; p.bias1 = a->bias1; p.hidden = a->hidden;
+    p.bias = a->bias2; p.resid = a->resid; p.ldr = a->ldr; p.out = a->out; p.ldo = a->ldo;
+    p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps; p.y = (bf16*)a->y; p.mean = a->mean; p.rstd = a->rstd;
+    p.row_scale = a->row_scale;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->M <= gv_cu_budget() * 64) return launch_panel<4, 8, 64, false, MODE_FWD, EP_MLP>(p, s, "gv_mlp_ln_fwd");
+    return launch_panel<7, 8, 64, false, MODE_FWD, EP_MLP>(p, s, "gv_mlp_ln_fwd");
 }
 
 extern "C" int gv_linear_ln_bwd(const gv_linear_ln_bwd_args* a, void* stream) {

@@ -333,6 +333,8 @@ class VitRunner:
         # are dead values: the last block runs them on the n_img CLS rows only (same loss and gradients; ~5.7 % fewer FLOPs of a
         # ViT-S DINO step).  GIPVIT_CLS_ONLY_LAST=0 computes every token of every block, as the reference's module + autograd do.
         self.cls_last = os.environ.get("GIPVIT_CLS_ONLY_LAST", "1") != "0"
+        # forward-only passes (teacher, inference) run the MLP as one launch; GIPVIT_FUSED_MLP=0 keeps fc1 / fc2 apart (A/B runs)
+        self.fused_mlp = os.environ.get("GIPVIT_FUSED_MLP", "1") != "0"
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
         self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
@@ -405,6 +407,16 @@ class VitRunner:
                     ops.linear(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, D, epilogue=E.EPI_BIAS | E.EPI_RESID,
                                bias=W.f(b + "attn.proj.bias"), resid=xa, row_scale=rs_a)
                 ops.layernorm_fwd(xb, W.f(b + "norm2.weight"), W.f(b + "norm2.bias"), T, D, y=G.xn2[s], mean=st[2], rstd=st[3])
+            if fused and self.fused_mlp and not G.save:
+                # a pass that keeps no activations (the teacher, inference): fc1 -> GELU -> fc2 -> + residual -> the next norm1 in ONE
+                # launch (gv_mlp_ln_fwd); the [T, 4 D] activation never reaches HBM
+                nxt = i + 1 < self.depth
+                nb, ns = f"blocks.{i + 1}.", G.slot(i + 1)
+                ops.mlp_ln_fwd(G.xn2[s], W.w(b + "mlp.fc1.weight"), W.f(b + "mlp.fc1.bias"), W.w(b + "mlp.fc2.weight"), xc, T, D, 4 * D,
+                               bias2=W.f(b + "mlp.fc2.bias"), resid=xb, gamma=W.f(nb + "norm1.weight") if nxt else None,
+                               beta=W.f(nb + "norm1.bias") if nxt else None, y=G.xn1[ns] if nxt else None,
+                               mean=G.stats[ns][0] if nxt else None, rstd=G.stats[ns][1] if nxt else None, row_scale=rs_m)
+                continue
             ops.linear(G.xn2[s], W.w(b + "mlp.fc1.weight"), G.h[s], T, 4 * D, D,
                        epilogue=E.EPI_BIAS | E.EPI_GELU | (E.EPI_SAVE_PRE if G.save else 0),   # a forward-only group keeps no pre-activation
                        bias=W.f(b + "mlp.fc1.bias"), aux_out=G.hp[s] if G.save else None)

@@ -207,6 +207,15 @@ def linear_ln_fwd(A, W, out, M: int, K: int, *, bias=None, resid=None, gamma=Non
     L.call("gv_linear_ln_fwd", a, _stream())
 
 
+def mlp_ln_fwd(A, W1, b1, W2, out, M: int, K: int, hidden: int, *, bias2=None, resid=None, gamma=None, beta=None, y=None, mean=None, rstd=None,
+               eps: float = 1e-6, N: int = 384, row_scale=None):
+    """out = resid + row_scale (GELU(A W1^T + b1) W2^T + bias2) (f32) and, with gamma, y / mean / rstd = LayerNorm of the new row, in one
+    launch; the hidden activation is not stored (forward-only passes); see gv_mlp_ln_fwd."""
+    a = L.gv_mlp_ln_fwd_args(A.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), _p(bias2), M, N, K, hidden, K, K, hidden,
+                             _p(resid), N, out.data_ptr(), N, _p(gamma), _p(beta), eps, _p(y), _p(mean), _p(rstd), _p(row_scale))
+    L.call("gv_mlp_ln_fwd", a, _stream())
+
+
 def linear_ln_bwd(dY, W, x, mean, rstd, gamma, g, gb, partials, M: int, K: int, *, g_init: bool = False, N: int = 384, gb_scale=None) -> int:
     """dXn = dY W (W stored [K, N]) fused with the LayerNorm backward it feeds; returns the number of partial blocks
     written (the n_blocks argument of ln_finalize); see gv_linear_ln_bwd."""

@@ -312,6 +312,20 @@ typedef struct {
 } gv_linear_ln_fwd_args;
 int gv_linear_ln_fwd(const gv_linear_ln_fwd_args* a, void* stream);
 
+/* Fused MLP forward (vit.pyc@L98-104 Mlp.forward inside Block.forward L146-152, for passes that save nothing: the DINO teacher,
+ * inference):  out = resid + row_scale * (GELU(A W1^T + bias1) W2^T + bias2)  [f32],  and -- with gamma -- y / mean / rstd =
+ * LayerNorm(out) as gv_linear_ln_fwd leaves them.  A bf16 [M, K], W1 bf16 [hidden, K], W2 bf16 [N, hidden]; N = 384,
+ * K % 64 == 0, hidden % 256 == 0.  The [M, hidden] activation lives in LDS, 256 columns at a time (a K-slice of fc2);
+ * results are bit-identical to gv_linear(BIAS | GELU) followed by gv_linear_ln_fwd.                                          */
+typedef struct {
+    const void* A; const void* W1; const float* bias1; const void* W2; const float* bias2;
+    int32_t M, N, K, hidden; int64_t lda, ldw1, ldw2;
+    const float* resid; int64_t ldr; float* out; int64_t ldo;
+    const float* gamma; const float* beta; float eps; void* y; float* mean; float* rstd;
+    const float* row_scale;
+} gv_mlp_ln_fwd_args;
+int gv_mlp_ln_fwd(const gv_mlp_ln_fwd_args* a, void* stream);
+
 /* bwd -- replaces the dX product of the Linear that CONSUMED a LayerNorm output (mlp.fc1 / attn.qkv:
  * dXn = dY . W with W the Linear weight stored [K = its out features, N = 384]) together with that LayerNorm's
  * backward (autograd of vit.pyc@L138,142; gv_layernorm_bwd's contract with dy = dXn kept in f32):

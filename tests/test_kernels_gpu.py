@@ -165,6 +165,47 @@ def test_linear_wide_panel(dev, M, N, K):
     close(Cf[:M], reff * rs[:, None] + resid, 1e-4, 1e-4, "row_scale")
 
 
+@pytest.mark.parametrize("M", [25216, 44160, 640, 300, 113])
+def test_mlp_ln_fwd(dev, M):
+    """gv_mlp_ln_fwd: fc1 -> GELU -> fc2 -> + residual -> LayerNorm in one launch (the hidden activation stays in LDS).  Bit-identical to
+    gv_linear (BIAS | GELU) followed by gv_linear_ln_fwd (same accumulation order, same GELU polynomial, same bf16 rounding of the
+    hidden activation), and within bf16 tolerances of the fp32 torch expression; one guard row behind every output."""
+    o, l = ops(), L()
+    D, Hd = 384, 1536
+    g = torch.Generator().manual_seed(41 + M)
+    A = (torch.randn(M, D, generator=g) * 0.7).to(dev).to(bf16)
+    W1 = (torch.randn(Hd, D, generator=g) * 0.05).to(dev).to(bf16)
+    W2 = (torch.randn(D, Hd, generator=g) * 0.03).to(dev).to(bf16)
+    b1, b2 = torch.randn(Hd, generator=g).to(dev) * 0.3, torch.randn(D, generator=g).to(dev) * 0.3
+    resid = torch.randn(M, D, generator=g).to(dev)
+    gam, bet = (1 + 0.2 * torch.randn(D, generator=g)).to(dev), (0.1 * torch.randn(D, generator=g)).to(dev)
+    rs = (torch.rand(M, generator=g) * 2).to(dev)
+    for row_scale, with_ln in ((None, True), (rs, True), (None, False)):
+        out = torch.full((M + 1, D), 9.0, dtype=f32, device=dev); y = torch.full((M + 1, D), 9.0, dtype=bf16, device=dev)
+        mean, rstd = torch.full((M + 1,), 9.0, device=dev), torch.full((M + 1,), 9.0, device=dev)
+        kw = dict(gamma=gam, beta=bet, y=y, mean=mean, rstd=rstd) if with_ln else {}
+        o.mlp_ln_fwd(A, W1, b1, W2, out, M, D, Hd, bias2=b2, resid=resid, row_scale=row_scale, **kw)
+        # the unfused pair
+        h = torch.empty(M, Hd, dtype=bf16, device=dev)
+        o.linear(A, W1, h, M, Hd, D, epilogue=l.EPI_BIAS | l.EPI_GELU, bias=b1)
+        out2 = torch.empty(M, D, dtype=f32, device=dev); y2 = torch.empty(M, D, dtype=bf16, device=dev)
+        mean2, rstd2 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        kw2 = dict(gamma=gam, beta=bet, y=y2, mean=mean2, rstd=rstd2) if with_ln else {}
+        o.linear_ln_fwd(h, W2, out2, M, Hd, bias=b2, resid=resid, row_scale=row_scale, **kw2)
+        assert torch.equal(out[:M], out2) and float(out[M].min()) == 9.0
+        if with_ln:
+            assert torch.equal(y[:M], y2) and torch.equal(mean[:M], mean2) and torch.equal(rstd[:M], rstd2)
+            assert float(y[M].float().min()) == 9.0 and float(mean[M]) == 9.0
+    # fp32 torch (bf16 hidden activation and bf16 operands: the tolerances of test_linear_epilogues)
+    hr = torch.nn.functional.gelu(A.float() @ W1.float().t() + b1)
+    ref = resid + hr @ W2.float().t() + b2
+    out = torch.empty(M, D, dtype=f32, device=dev); y = torch.empty(M, D, dtype=bf16, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    o.mlp_ln_fwd(A, W1, b1, W2, out, M, D, Hd, bias2=b2, resid=resid, gamma=gam, beta=bet, y=y, mean=mean, rstd=rstd)
+    close(out, ref, 1e-2, 2e-2, "fused MLP vs fp32 torch")
+    close(y, torch.nn.functional.layer_norm(ref, (D,), gam, bet, 1e-6), 2e-2, 3e-2, "fused MLP: LayerNorm row")
+
+
 def test_linear_pos_epilogue(dev):
     """patch-embed epilogue: rows remapped past the CLS slot, pos-embed added."""
     o, l = ops(), L()
