@@ -377,7 +377,8 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
             }
         }
     }
-    if (g_plan) { g_plan_bytes = p.ksplit > 1 ? (long)p.ksplit * a->M * a->N * 4 : 0; return GV_OK; }
+    // plan mode (gv_workspace_bytes) applies the launch's own fit test below: a slab that does not fit the scratch is not used (atomics)
+    if (g_plan) { const long need = p.ksplit > 1 ? (long)p.ksplit * a->M * a->N * 4 : 0; g_plan_bytes = need <= a->workspace_bytes ? need : 0; return GV_OK; }
     bool slab = false;
     if (p.ksplit > 1 && a->workspace && (long)p.ksplit * a->M * a->N * 4 <= a->workspace_bytes && gv_aligned(a->workspace, 16)) {
         p.slab = a->workspace;

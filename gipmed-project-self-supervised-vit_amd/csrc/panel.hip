@@ -749,9 +749,7 @@ __global__ __launch_bounds__(NW * 64, 2) void panel_kernel(const PanelP p) {
 // rows per workgroup for M rows: the smallest supported FM that covers M in as few full rounds of 256 workgroups as possible
 constexpr int FM_SET8[] = {4, 7, 9, 11, 12};
 int cu_budget() { return gv_cu_budget(); }       // 256, or 256 - C under a data-parallel run that leaves C CUs to RCCL (gv_common.h)
-int fm_floor() { static const int f = [] { const char* e = getenv("GIPVIT_FM_FLOOR"); return e ? atoi(e) : 0; }(); return f; }
 int pick_fm(int M) {
-    if (fm_floor() >= 11 && M >= 8192) return fm_floor() >= 12 ? 12 : 11;
     const int m16 = (M + 15) / 16;
     const int rounds = (m16 + cu_budget() * 12 - 1) / (cu_budget() * 12);
     const int need = (m16 + cu_budget() * rounds - 1) / (cu_budget() * rounds);
@@ -767,7 +765,6 @@ int wide_grid(int M, int BM, int ncb) {
 // ... and the smallest supported FM whose WORKING workgroups (ncb per group of panels; the grid's padding to 8 ncb exits at once)
 // fit one round of the CU budget; 12 (several rounds) for larger M
 int pick_fm_wide(int M, int ncb) {
-    if (fm_floor() >= 11 && M >= 8192) return fm_floor() >= 12 ? 12 : 11;
     for (int fm : FM_SET8) {
         const int P = (M + 16 * fm - 1) / (16 * fm), groups = (P + ncb - 1) / ncb;
         if (groups * ncb <= cu_budget() && wide_grid(M, 16 * fm, ncb) <= 256) return fm;

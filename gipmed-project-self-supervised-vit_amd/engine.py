@@ -936,7 +936,9 @@ class DinoEngine:
         self.g_stu.set_drop(per_img)
 
     def set_dropout(self, p: float, seed: int = 0):
-        """--drop for the STUDENT's next step (the teacher runs in eval mode): probability and this step's 32-bit seed; p = 0 switches it off."""
+        """--drop for the STUDENT's next step (the teacher runs in eval mode): probability and this step's 32-bit seed; p = 0 switches it off.
+        Under gradient accumulation every micro-batch of the step derives its own seed from this one (forward_backward)."""
+        self._drop = (float(p), int(seed) & 0xFFFFFFFF) if p else None
         self.g_stu.set_dropout(p, seed)
 
     def set_hyper(self, lr=None, wd=None, momentum_teacher=None, teacher_temp=None, n_micro: int = 1):
@@ -966,6 +968,8 @@ class DinoEngine:
         a = self.arena
         mj, mn = micro
         first, last = mj == 0, mj == mn - 1
+        if mn > 1 and getattr(self, "_drop", None):      # micro-batches of one step must not share their dropout masks
+            self.g_stu.set_dropout(self._drop[0], ops.dropout_site_seed(self._drop[1], 15, mj))
         t_src, t_win, s_src, s_win = tiles_u8, [self.gwins], tiles_u8, self.s_wins
         if boxes is not None and fill is not None:
             raise ValueError("fill boxes are tile coordinates: they cannot be combined with re-cut random crops (boxes)")

@@ -35,6 +35,7 @@ import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import csv
+import json
 import logging
 import os
 import sys
@@ -409,6 +410,10 @@ def main(argv=None):
             ex["state_dict_ema"] = eng.state_dict(ema=True)     # timm CheckpointSaver key
         if drop_sampler is not None:
             ex["drop_path_rng"] = drop_sampler.state_dict()     # a resumed run continues the mask stream
+        # ... and the other host-side draw streams (--drop step seeds, random-resized-crop boxes, view augmentation), as JSON
+        # strings of numpy's bit-generator state: plain str, loads with weights_only=True
+        streams = {"drop": drop_rng, "crops": getattr(sampler, "rng", None), "views": getattr(view_sampler, "rng", None)}
+        ex["host_rng"] = {k: json.dumps(g.bit_generator.state) for k, g in streams.items() if g is not None}
         if eng.scaler is not None:
             ex["amp_scaler"] = eng.scaler.state_dict()          # timm CheckpointSaver(amp_scaler=loss_scaler) key, train.py:585-602
         return ex
@@ -432,6 +437,10 @@ def main(argv=None):
     if args.drop:
         import numpy as np
         drop_rng = np.random.default_rng(args.seed + 7919 * rank + 11)
+    if args.resume and isinstance(ck.get("host_rng"), dict):     # continue the draw streams where the saved run left them
+        for k, g in (("drop", drop_rng), ("crops", getattr(sampler, "rng", None)), ("views", getattr(view_sampler, "rng", None))):
+            if g is not None and k in ck["host_rng"]:
+                g.bit_generator.state = json.loads(ck["host_rng"][k])
     cur_lr = lr
     # ---- epoch loop (train.py:905-977) / step loop (988-1143)
     for epoch in range(start_epoch, args.epochs):
