@@ -78,10 +78,10 @@ gv_linear_ln_bwd_args = _struct("gv_linear_ln_bwd_args", [
 GV_ATTN_MAX_SEG = 4
 gv_attention_fwd_varlen_args = _struct("gv_attention_fwd_varlen_args", [
     ("qkv", vp), ("o", vp), ("n_seg", i32), ("n_img", i32 * GV_ATTN_MAX_SEG), ("N", i32 * GV_ATTN_MAX_SEG), ("lse", vp * GV_ATTN_MAX_SEG),
-    ("H", i32), ("scale", f32)])
+    ("H", i32), ("scale", f32), ("q_limit", i32)])
 gv_attention_bwd_varlen_args = _struct("gv_attention_bwd_varlen_args", [
     ("qkv", vp), ("o", vp), ("d_o", vp), ("dqkv", vp), ("n_seg", i32), ("n_img", i32 * GV_ATTN_MAX_SEG), ("N", i32 * GV_ATTN_MAX_SEG),
-    ("lse", vp * GV_ATTN_MAX_SEG), ("H", i32), ("scale", f32)])
+    ("lse", vp * GV_ATTN_MAX_SEG), ("H", i32), ("scale", f32), ("q_limit", i32)])
 gv_expand_rows_args = _struct("gv_expand_rows_args", [("per_img", vp), ("row_img", vp), ("rows", vp), ("n_rep", i32), ("n_img", i32), ("T", i32)])
 GV_DW_GROUP_MAX = 4
 gv_dw_problem = _struct("gv_dw_problem", [("dY", vp), ("ldy", i64), ("X", vp), ("ldx", i64), ("dW", vp), ("ldw", i64), ("colsum_dy", vp),
@@ -89,9 +89,9 @@ gv_dw_problem = _struct("gv_dw_problem", [("dY", vp), ("ldy", i64), ("X", vp), (
 gv_linear_dw_group_args = _struct("gv_linear_dw_group_args", [("prob", gv_dw_problem * GV_DW_GROUP_MAX), ("n", i32), ("K", i32),
                                                               ("workspace", vp), ("workspace_bytes", i64)])
 gv_attention_fwd_args = _struct("gv_attention_fwd_args", [
-    ("qkv", vp), ("o", vp), ("lse", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32)])
+    ("qkv", vp), ("o", vp), ("lse", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32), ("q_limit", i32)])
 gv_attention_bwd_args = _struct("gv_attention_bwd_args", [
-    ("qkv", vp), ("o", vp), ("d_o", vp), ("lse", vp), ("dqkv", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32)])
+    ("qkv", vp), ("o", vp), ("d_o", vp), ("lse", vp), ("dqkv", vp), ("n_img", i32), ("N", i32), ("H", i32), ("scale", f32), ("q_limit", i32)])
 gv_cls_rows_args = _struct("gv_cls_rows_args", [("x", vp), ("cls", vp), ("pos", vp), ("n_img", i32), ("N", i32), ("D", i32)])
 gv_tokens_bwd_args = _struct("gv_tokens_bwd_args", [
     ("g", vp), ("gpatch", vp), ("dpos", vp), ("dcls", vp), ("n_img", i32), ("N", i32), ("D", i32), ("accumulate", i32)])

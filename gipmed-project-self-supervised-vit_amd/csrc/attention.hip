@@ -102,6 +102,9 @@ __device__ __forceinline__ void attn_fwd_body(const gv_attention_fwd_args a, con
     GV_LDS char* Vimg = smem + (lp * 2 + 1) * IMG;
     const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
     const float c = a.scale * 1.4426950408889634f;
+    // q_limit: only the first query rows are wanted -- whole 32-row groups, so that the backward with the same limit finds o / lse
+    // valid for every row its first half-step touches
+    const int QE = (a.q_limit > 0 && ((a.q_limit + 31) & ~31) < N) ? ((a.q_limit + 31) & ~31) : N;
 
     // this wave's Q fragments for all its query blocks: issued BEFORE the staging wait so the
     // global-load latencies of Q, K and V overlap
@@ -125,7 +128,7 @@ __device__ __forceinline__ void attn_fwd_body(const gv_attention_fwd_args a, con
     auto round = [&](auto RDc) {
         constexpr int rd = decltype(RDc)::value;
         const int qb = wq + rd * WPP;
-        if (qb >= NQB || qb * QB >= N) return;
+        if (qb >= NQB || qb * QB >= QE) return;
         f32x4 s[NKT][QT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -379,7 +382,10 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
 
     // 64 queries per barrier pair: phase A runs twice (two 32-query halves, registers as for one) and
     // fills both halves of the dS^T image, phase B then has 16 dQ tiles to spread over the waves
-    const int nqc2 = (N + 32 * QH - 1) / (32 * QH);
+    // q_limit: d_o is zero behind the first q_limit query rows -> whole 32-query halves behind them contribute nothing to dK / dV
+    // and have dQ = 0: they are skipped (their dQ rows are zero-filled at the end)
+    const int QE = (a.q_limit > 0 && ((a.q_limit + 31) & ~31) < N) ? ((a.q_limit + 31) & ~31) : N;
+    const int nqc2 = (QE + 32 * QH - 1) / (32 * QH);
     for (int qc2 = 0; qc2 < nqc2; ++qc2) {
         // NDS = 2: step i writes image i & 1.  Its readers (phase B of step i) come before phase A of step i + 1 in every wave's
         // program order, hence before the barrier of step i + 1 -- and image i & 1 is next written in step i + 2, behind that barrier
@@ -387,7 +393,7 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
 #pragma unroll
         for (int half = 0; half < QH; ++half) {
             const int qc = qc2 * QH + half;
-            if (qc * 32 >= N) break;
+            if (qc * 32 >= QE) break;
             // ---- phase A: S, dP for [32 q] x [this wave's keys]
             f32x4 s[2][KT], dp[2][KT];
 #pragma unroll
@@ -458,7 +464,7 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
         // ---- phase B: dQ^T[d][q] = sum_key K[key][d] dS[q][key]; 16 (qt, dt) tiles over the pair's waves
         for (int tile = kb; tile < 8 * QH; tile += NKB) {
             const int qt = tile >> 2, dt = tile & 3;
-            if (qc2 * 32 * QH + qt * 16 >= N) continue;
+            if (qc2 * 32 * QH + qt * 16 >= QE) continue;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NK32; ++ks) {
@@ -476,6 +482,10 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
                     bf16x4{(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
         }
         if constexpr (NDS == 1) __syncthreads();
+    }
+    if (valid) {        // skipped queries: dQ = 0 (4 rows x 128 B per wave-instruction)
+        for (int q = QE + kb * 4 + g; q < N; q += NKB * 4)
+            *(bf16x4*)((bf16*)a.dqkv + ((long)img * N + q) * ld + h * 64 + li * 4) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
     }
     // ---- dK, dV: lane = key, rows d = 16 dt + 4 g + r
     if (valid) {
@@ -542,6 +552,7 @@ extern "C" int gv_attention_fwd_varlen(const gv_attention_fwd_varlen_args* v, vo
         seg[i].qkv = (const char*)v->qkv + row * 3 * v->H * 64 * 2;
         seg[i].o = (char*)v->o + row * v->H * 64 * 2;
         seg[i].lse = v->lse[i]; seg[i].n_img = v->n_img[i]; seg[i].N = v->N[i]; seg[i].H = v->H; seg[i].scale = v->scale;
+        seg[i].q_limit = v->q_limit;
         row += (long)v->n_img[i] * v->N[i];
     }
     // one launch for a long + a short segment (either order); any other mix runs one launch per segment
@@ -583,6 +594,7 @@ extern "C" int gv_attention_bwd_varlen(const gv_attention_bwd_varlen_args* v, vo
         seg.d_o = (const char*)v->d_o + row * v->H * 64 * 2;
         seg.dqkv = (char*)v->dqkv + row * 3 * v->H * 64 * 2;
         seg.lse = v->lse[i]; seg.n_img = v->n_img[i]; seg.N = v->N[i]; seg.H = v->H; seg.scale = v->scale;
+        seg.q_limit = v->q_limit;
         if (int rc = gv_attention_bwd(&seg, stream)) return rc;
         row += (long)v->n_img[i] * v->N[i];
     }

@@ -386,13 +386,15 @@ class VitRunner:
             if not fused or i == 0:
                 ops.layernorm_fwd(xa, W.f(b + "norm1.weight"), W.f(b + "norm1.bias"), T, D, y=G.xn1[s], mean=st[0], rstd=st[1])
             ops.linear(G.xn1[s], W.w(b + "attn.qkv.weight"), G.qkv[s], T, 3 * D, D, epilogue=E.EPI_BIAS, bias=W.f(b + "attn.qkv.bias"))
+            # the last block under the CLS-only tail: only the CLS query's attention output is used (row 0 of every image)
+            ql = 1 if (self._cls_tail(G) and i == self.depth - 1 and os.environ.get("GIPVIT_CLS_QLIMIT", "1") != "0") else 0
             if len(G.segs) > 1 and os.environ.get("GIPVIT_VARLEN_ATTN", "1") != "0":
                 # the crop lengths of a multi-crop pass in ONE call (gv_attention_fwd_varlen: the 37-token pairs fill the 197-token
                 # launch's half-empty last round); GIPVIT_VARLEN_ATTN=0 keeps one launch per segment for A/B runs
-                ops.attention_fwd_varlen(G.qkv[s], G.o[s], [(sg.n_img, sg.N, sg.lse[s]) for sg in G.segs], H, self.scale)
+                ops.attention_fwd_varlen(G.qkv[s], G.o[s], [(sg.n_img, sg.N, sg.lse[s]) for sg in G.segs], H, self.scale, q_limit=ql)
             else:
                 for sg in G.segs:
-                    ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s])
+                    ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s], q_limit=ql)
             if self._cls_tail(G) and i == self.depth - 1:
                 self._last_block_tail_fwd(W, G, i, xa, fused)
                 break
@@ -636,7 +638,9 @@ class VitRunner:
                 ops.linear(G.c_gb_att, W.w(b + "attn.proj.weight"), G.c_do, n, D, D, trans_b=True)
                 G.scatter_cls(G.c_do, G.do)           # (G.do was zeroed by prepare_backward)
                 G.scatter_cls(G.c_g, G.g)                 # (G.g was zeroed above)
-                ops.attention_bwd_varlen(G.qkv[i], G.o[i], G.do, dqkv, [(sg.n_img, sg.N, sg.lse[i]) for sg in G.segs], H, self.scale)
+                # dO is zero behind every image's CLS row: the attention backward skips the other queries (their dQ rows come out zero)
+                ops.attention_bwd_varlen(G.qkv[i], G.o[i], G.do, dqkv, [(sg.n_img, sg.N, sg.lse[i]) for sg in G.segs], H, self.scale,
+                                         q_limit=1 if os.environ.get("GIPVIT_CLS_QLIMIT", "1") != "0" else 0)
                 ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
                        W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None,
                        dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])

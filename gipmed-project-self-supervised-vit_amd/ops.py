@@ -238,31 +238,31 @@ def linear_dw_group(problems, K: int, workspace):
     L.call("gv_linear_dw_group", a, _stream())
 
 
-def attention_fwd(qkv, n_img: int, N: int, H: int, scale: float, o=None, lse=None):
+def attention_fwd(qkv, n_img: int, N: int, H: int, scale: float, o=None, lse=None, q_limit: int = 0):
     dev = qkv.device
     o = torch.empty(n_img * N, H * 64, dtype=qkv.dtype, device=dev) if o is None else o
     lse = torch.empty(n_img, H, N, dtype=f32, device=dev) if lse is None else lse
-    a = L.gv_attention_fwd_args(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), n_img, N, H, scale)
+    a = L.gv_attention_fwd_args(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), n_img, N, H, scale, q_limit)
     if o.dtype != qkv.dtype:
         raise TypeError(f"attention_fwd: qkv is {qkv.dtype} but o is {o.dtype}")
     L.call("gv_attention_fwd" + _sfx(qkv), a, _stream())
     return o, lse
 
 
-def attention_fwd_varlen(qkv, o, segments, H: int, scale: float):
+def attention_fwd_varlen(qkv, o, segments, H: int, scale: float, q_limit: int = 0):
     """All segments of a token-concatenated row space in one call: ``segments`` = [(n_img, N, lse f32 [n_img, H, N]), ...] in row
     order; qkv [T, 3 H 64], o [T, H 64].  bf16: gv_attention_fwd_varlen (a long + a short segment share ONE launch); the fp32
     operand mode runs one call per segment."""
     if qkv.dtype != bf16 or len(segments) > L.GV_ATTN_MAX_SEG:
         row = 0
         for n_img, N, lse in segments:
-            attention_fwd(qkv[row:row + n_img * N], n_img, N, H, scale, o=o[row:row + n_img * N], lse=lse)
+            attention_fwd(qkv[row:row + n_img * N], n_img, N, H, scale, o=o[row:row + n_img * N], lse=lse, q_limit=q_limit)
             row += n_img * N
         return
     if o.dtype != qkv.dtype:
         raise TypeError(f"attention_fwd_varlen: qkv is {qkv.dtype} but o is {o.dtype}")
     a = L.gv_attention_fwd_varlen_args()
-    a.qkv, a.o, a.n_seg, a.H, a.scale = qkv.data_ptr(), o.data_ptr(), len(segments), H, scale
+    a.qkv, a.o, a.n_seg, a.H, a.scale, a.q_limit = qkv.data_ptr(), o.data_ptr(), len(segments), H, scale, q_limit
     rows = 0
     for i, (n_img, N, lse) in enumerate(segments):
         assert lse.dtype == f32 and lse.numel() >= n_img * H * N
@@ -272,16 +272,17 @@ def attention_fwd_varlen(qkv, o, segments, H: int, scale: float):
     L.call("gv_attention_fwd_varlen", a, _stream())
 
 
-def attention_bwd(qkv, o, d_o, lse, n_img: int, N: int, H: int, scale: float, dqkv=None):
+def attention_bwd(qkv, o, d_o, lse, n_img: int, N: int, H: int, scale: float, dqkv=None, q_limit: int = 0):
+    """``q_limit`` > 0: d_o is zero behind the first q_limit query rows of every image -- those queries are skipped (gv_attention_bwd)."""
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
-    a = L.gv_attention_bwd_args(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), n_img, N, H, scale)
+    a = L.gv_attention_bwd_args(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), n_img, N, H, scale, q_limit)
     if not (o.dtype == d_o.dtype == dqkv.dtype == qkv.dtype):
         raise TypeError("attention_bwd: qkv / o / d_o / dqkv must share one dtype")
     L.call("gv_attention_bwd" + _sfx(qkv), a, _stream())
     return dqkv
 
 
-def attention_bwd_varlen(qkv, o, d_o, dqkv, segments, H: int, scale: float):
+def attention_bwd_varlen(qkv, o, d_o, dqkv, segments, H: int, scale: float, q_limit: int = 0):
     """Backward of all segments of a token-concatenated row space in one call: ``segments`` = [(n_img, N, lse), ...] as for
     attention_fwd_varlen; qkv / dqkv [T, 3 H 64], o / d_o [T, H 64].  bf16: gv_attention_bwd_varlen; the fp32 operand mode runs
     one call per segment."""
@@ -289,13 +290,14 @@ def attention_bwd_varlen(qkv, o, d_o, dqkv, segments, H: int, scale: float):
         row = 0
         for n_img, N, lse in segments:
             r = slice(row, row + n_img * N)
-            attention_bwd(qkv[r], o[r], d_o[r], lse, n_img, N, H, scale, dqkv=dqkv[r])
+            attention_bwd(qkv[r], o[r], d_o[r], lse, n_img, N, H, scale, dqkv=dqkv[r], q_limit=q_limit)
             row += n_img * N
         return dqkv
     if not (o.dtype == d_o.dtype == dqkv.dtype == qkv.dtype):
         raise TypeError("attention_bwd_varlen: qkv / o / d_o / dqkv must share one dtype")
     a = L.gv_attention_bwd_varlen_args()
     a.qkv, a.o, a.d_o, a.dqkv, a.n_seg, a.H, a.scale = qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), dqkv.data_ptr(), len(segments), H, scale
+    a.q_limit = q_limit
     rows = 0
     for i, (n_img, N, lse) in enumerate(segments):
         assert lse.dtype == f32 and lse.numel() >= n_img * H * N

@@ -361,6 +361,9 @@ int gv_expand_rows(const gv_expand_rows_args* a, void* stream);
 typedef struct {
     const void* qkv; void* o; float* lse;
     int32_t n_img, N, H; float scale;
+    int32_t q_limit;      /* > 0: only the first q_limit query rows of every image are needed (rounded up to 32): o / lse rows behind
+                           * them are left untouched.  The last block of a ViT whose forward returns the CLS row (vit.pyc@L248-253)
+                           * asks for 1.  0 = every query.  (The _f32 entry point computes every query.)                            */
 } gv_attention_fwd_args;
 int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream);
 
@@ -375,6 +378,7 @@ typedef struct {
     int32_t n_seg; int32_t n_img[GV_ATTN_MAX_SEG]; int32_t N[GV_ATTN_MAX_SEG];
     float* lse[GV_ATTN_MAX_SEG];
     int32_t H; float scale;
+    int32_t q_limit;      /* as gv_attention_fwd_args.q_limit, for every segment */
 } gv_attention_fwd_varlen_args;
 int gv_attention_fwd_varlen(const gv_attention_fwd_varlen_args* a, void* stream);
 
@@ -382,6 +386,10 @@ typedef struct {
     const void* qkv; const void* o; const void* d_o; const float* lse;
     void* dqkv;           /* bf16 [n_img*N, 3, H, 64]                        */
     int32_t n_img, N, H; float scale;
+    int32_t q_limit;      /* > 0: d_o is zero behind the first q_limit query rows of every image (the caller guarantees it for the rows
+                           * up to the next multiple of 32; rows behind that are not read): those queries are skipped and their dQ rows
+                           * are written as zeros.  qkv / o / lse must be valid for the rows up to that multiple of 32 (what
+                           * gv_attention_fwd with the same q_limit leaves).  0 = every query.                                      */
 } gv_attention_bwd_args;
 int gv_attention_bwd(const gv_attention_bwd_args* a, void* stream);
 
@@ -394,6 +402,7 @@ typedef struct {
     int32_t n_seg; int32_t n_img[GV_ATTN_MAX_SEG]; int32_t N[GV_ATTN_MAX_SEG];
     const float* lse[GV_ATTN_MAX_SEG];
     int32_t H; float scale;
+    int32_t q_limit;      /* as gv_attention_bwd_args.q_limit, for every segment */
 } gv_attention_bwd_varlen_args;
 int gv_attention_bwd_varlen(const gv_attention_bwd_varlen_args* a, void* stream);
 

@@ -668,6 +668,33 @@ def test_attention_bwd_varlen(dev, segs):
         row += n * N
 
 
+@pytest.mark.parametrize("N,H,n_img,ql", [(197, 6, 5, 1), (37, 6, 9, 1), (197, 3, 2, 40), (257, 6, 2, 1), (65, 12, 3, 33), (17, 3, 4, 1)])
+def test_attention_q_limit(dev, N, H, n_img, ql):
+    """q_limit (the last block of a ViT whose forward returns the CLS row): the forward computes only the first query rows (whole
+    32-row groups), the backward skips every query behind them when dO is zero there.  Bit-equal to the full kernels on the rows that
+    are computed (forward) and on every gradient (backward: dK, dV, the kept dQ rows; the skipped dQ rows are exactly zero)."""
+    o, scale = ops(), 0.125
+    g = torch.Generator().manual_seed(N + ql)
+    qkv = torch.randn(n_img * N, 3 * H * 64, generator=g).to(dev).to(bf16)
+    full_o, full_lse = o.attention_fwd(qkv, n_img, N, H, scale)
+    out = torch.full_like(full_o, 7.0); lse = torch.full_like(full_lse, 7.0)
+    o.attention_fwd(qkv, n_img, N, H, scale, o=out, lse=lse, q_limit=ql)
+    qe = min(N, (ql + 31) // 32 * 32)
+    ov, fv = out.view(n_img, N, H * 64), full_o.view(n_img, N, H * 64)
+    assert torch.equal(ov[:, :qe], fv[:, :qe]) and torch.equal(lse[:, :, :qe], full_lse[:, :, :qe])
+    if qe < N:
+        assert float(ov[:, qe:].float().min()) == 7.0 and float(lse[:, :, qe:].min()) == 7.0       # untouched
+    d_o = torch.zeros(n_img, N, H * 64, dtype=bf16, device=dev)
+    d_o[:, :ql] = torch.randn(n_img, ql, H * 64, generator=g).to(dev).to(bf16)
+    d_o = d_o.view(n_img * N, H * 64)
+    ref = o.attention_bwd(qkv, full_o, d_o, full_lse, n_img, N, H, scale)
+    got = torch.full_like(ref, 5.0)
+    o.attention_bwd(qkv, out, d_o, lse, n_img, N, H, scale, dqkv=got, q_limit=ql)       # o / lse as the limited forward left them
+    assert torch.equal(got, ref)
+    if qe < N:
+        assert float(got.view(n_img, N, 3, H * 64)[:, qe:, 0].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", [bf16, f32])
 def test_dropout_kernels(dev, dt):
     """gv_dropout / gv_dropout_add: the counter-based keep mask of (seed, element index) equals the oracle's numpy restatement bit for
