@@ -667,15 +667,17 @@ class VitRunner:
                 drop_branch_grad(gb_att, i, 1, W.g(b + "attn.proj.bias"))
             ops.linear(gb_att, W.w(b + "attn.proj.weight"), G.do, T, D, D, trans_b=True)
             ops.attention_bwd_varlen(G.qkv[i], G.o[i], G.do, dqkv, [(sg.n_img, sg.N, sg.lse[i]) for sg in G.segs], H, self.scale)
-            join(done_grp[par ^ 1])                       # block i + 1's group read gb_next (its MLP-half dY)
-            ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
-                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if (i > 0 and not dp) else None,
-                   dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])
+            # the block's four dY operands are final once the attention backward has run: its weight gradients go to the side stream
+            # BEFORE the last kernel of the block's dX chain (which only reads dqkv), one kernel earlier than the chain's end
             probs = [(gb_mlp, G.h[i], W.g(b + "mlp.fc2.weight"), None),
                      (dh, G.xn2[i], W.g(b + "mlp.fc1.weight"), W.g(b + "mlp.fc1.bias")),
                      (gb_att, G.o[i], W.g(b + "attn.proj.weight"), None),
                      (dqkv, G.xn1[i], W.g(b + "attn.qkv.weight"), W.g(b + "attn.qkv.bias"))]
             done_grp[par] = dw_group(probs)
+            join(done_grp[par ^ 1])                       # block i + 1's group read gb_next (its MLP-half dY)
+            ln_bwd(G.dxn, G.x[2 * i], st[0], st[1], W.f(b + "norm1.weight"), gb_next,
+                   W.g(b + "norm1.weight"), W.g(b + "norm1.bias"), W.g(f"blocks.{i - 1}.mlp.fc2.bias") if (i > 0 and not dp) else None,
+                   dx_of=(dqkv, W.w(b + "attn.qkv.weight"), 3 * D), gb_scale=None if (rs is None or i == 0) else rs[i - 1, 1])
             report(i)
         join(done_grp[0]); join(done_grp[1])
 
