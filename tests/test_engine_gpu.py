@@ -120,6 +120,44 @@ def test_dino_forward_backward_parity_configs(dev, arch, n_local, B, K):
 
 
 @gpu
+@pytest.mark.parametrize("arch,D", [("vit_small", 384), ("vit_tiny", 192)])
+def test_cls_only_last_block_equals_every_token(dev, arch, D):
+    """The last block's projection / MLP (and their backward) on the CLS rows only, with the last attention limited to the CLS query
+    (engine.VitRunner.cls_last, the default), against the same engine computing every token of every block as the reference's module +
+    autograd do: the skipped values are dead (VisionTransformer.forward returns x[:, 0], vit.pyc@L248-253), so loss, logits and every
+    parameter gradient agree to the rounding of the different summation orders (three weight gradients of the last block reduce over
+    n_img rows instead of T rows of which all but n_img are zero).  vit_small runs the fused full-row path, vit_tiny the unfused one."""
+    from gipvit.engine import DinoEngine
+    from oracle import vit_oracle as vo
+    K, B = 2048, 4
+    p, hp = vo.init_vit(arch, 224, 0, seed=0), vo.init_dino_head(D, K, seed=1)
+    tiles = vo.synth_tiles(B, 256, seed=5).to(dev)
+    out = {}
+    for cls_last in (True, False):
+        eng = DinoEngine(arch=arch, img_size=224, out_dim=K, batch=B, device=dev)
+        eng.vit.cls_last = cls_last
+        eng.load_state(p, hp)
+        eng.set_hyper()
+        eng.forward_backward(tiles)
+        torch.cuda.synchronize()
+        assert eng.vit._cls_tail(eng.g_stu) == cls_last
+        out[cls_last] = (float(eng.loss), eng.hb_s.logits.clone(), eng.hb_t.logits.clone(), {n: g.clone() for n, g in eng.grads().items()})
+    (l1, s1, t1, g1), (l0, s0, t0, g0) = out[True], out[False]
+    assert abs(l1 - l0) <= 2e-5, (l1, l0)
+    assert float((s1 - s0).abs().max()) <= 2e-3 * float(s0.abs().max()) and float((t1 - t0).abs().max()) <= 2e-3 * float(t0.abs().max())
+    worst = ("", 0.0)
+    for n in g0:
+        a, b = g1[n].double(), g0[n].double()
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, n
+            continue
+        rel = float((a - b).norm() / b.norm())
+        if rel > worst[1]:
+            worst = (n, rel)
+    assert worst[1] <= 5e-3, worst
+
+
+@gpu
 @pytest.mark.parametrize("arch,D,mb", [("vit_tiny", 192, 1), ("vit_base", 768, 8)])
 def test_dino_micro_batches_equal_full_batch(dev, arch, D, mb):
     """Gradient accumulation (BASELINE config 5: ViT-B, 512 tiles per GPU in micro-batches): one optimizer step
