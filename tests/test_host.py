@@ -245,6 +245,29 @@ def test_reduction_plan_tiles_the_arena_in_backward_order():
     assert reduction_plan((0, 50), {1: (50, 80), 0: (80, 100)}, 130, bucket_bytes=1 << 30) == [("head", 0, 50), (1, 50, 80), ("end", 80, 130)]
 
 
+def test_comm_setup_environment_contract(monkeypatch):
+    """dist.comm_setup: nothing is touched at world size 1, for the gloo rehearsal transport or without GIPVIT_COMM_CUS (the
+    default: RCCL's own channel count, launches sized for the whole chip); GIPVIT_COMM_CUS = C sizes the library for 256 - C and
+    caps RCCL to C channels, and values already in the environment win."""
+    import os
+    from gipvit.dist import comm_setup
+    for k in ("GIPVIT_COMM_CUS", "GIPVIT_CU_BUDGET", "NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS"):
+        monkeypatch.delenv(k, raising=False)
+    assert comm_setup(1, "nccl") == {"comm_cus": 0, "cu_budget": 256}
+    assert comm_setup(8, "gloo") == {"comm_cus": 0, "cu_budget": 256}
+    info = comm_setup(8, "nccl")
+    assert info["comm_cus"] == 0 and info["cu_budget"] == 256 and "NCCL_MAX_NCHANNELS" not in os.environ and "GIPVIT_CU_BUDGET" not in os.environ
+    monkeypatch.setenv("GIPVIT_COMM_CUS", "16")
+    monkeypatch.setenv("GIPVIT_CU_BUDGET", "248")              # set by the caller: kept (and the library may already be loaded then)
+    info = comm_setup(8, "nccl")
+    assert info["comm_cus"] == 16 and info["cu_budget"] == 248 and os.environ["NCCL_MAX_NCHANNELS"] == "16" and os.environ["NCCL_MIN_NCHANNELS"] == "4"
+    monkeypatch.setenv("GIPVIT_COMM_CUS", "2")
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "12")
+    monkeypatch.delenv("NCCL_MIN_NCHANNELS")
+    info = comm_setup(2, "nccl")
+    assert info["nccl_max_nchannels"] == "12" and os.environ["NCCL_MIN_NCHANNELS"] == "2"
+
+
 def test_train_cli_keeps_reference_surface(tmp_path):
     """Every flag of the reference trainer parses (documented command lines of
     train_instruct.txt:16-34 included), YAML -c defaults work, and without a GPU the driver
