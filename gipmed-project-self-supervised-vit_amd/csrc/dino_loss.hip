@@ -18,10 +18,14 @@ constexpr int MAXV = 16, MAXG = 4;
 template <typename DT> __device__ __forceinline__ float ex(float x) { if constexpr (sizeof(DT) == 4) return expf(x); else return __expf(x); }
 template <typename DT> __device__ __forceinline__ float lg(float x) { if constexpr (sizeof(DT) == 4) return logf(x); else return __logf(x); }
 
-// one block per logits row: running max / sum-exp of the temperature-scaled row
-template <typename DT>
-__global__ __launch_bounds__(256) void row_stats_kernel(gv_dino_loss_args a) {
-    __shared__ float red_m[4], red_s[4];
+// one block per logits row: running max / sum-exp of the temperature-scaled row.  A thread takes RS_U 16-B pieces per trip, both
+// requested before the first is used, folds them into one maximum and rescales its running sum once per trip.  Measured at the
+// headline shape (768 rows x 256 KB, tools/loss_bench.py, whole call): one piece per trip 101 us, two 93, four 102, eight 119;
+// 512- / 1024-thread blocks 92 - 98
+template <typename DT, int NT, int RS_U>
+__global__ __launch_bounds__(NT) void row_stats_kernel(gv_dino_loss_args a) {
+    constexpr int NWV = NT / 64;
+    __shared__ float red_m[NWV], red_s[NWV];
     const int row = blockIdx.x;
     const int ns = a.V * a.B;
     const bool teacher = row >= ns;
@@ -29,30 +33,48 @@ __global__ __launch_bounds__(256) void row_stats_kernel(gv_dino_loss_args a) {
     const float* x = teacher ? a.teacher + (long)(row - ns) * a.K : a.student + (long)row * a.K;
     const float inv_t = 1.0f / (teacher ? a.teacher_temp : a.student_temp);
     float m = -INFINITY, s = 0.f;
-    for (int k = threadIdx.x * 4; k < a.K; k += 1024) {
-        f32x4 v = *(const f32x4*)(x + k);
-        if (teacher) { f32x4 c = *(const f32x4*)(a.center + k); v -= c; }
-        v *= inv_t;
-        const float lm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        if (lm > m) { s *= ex<DT>(m - lm); m = lm; }
-        s += ex<DT>(v[0] - m) + ex<DT>(v[1] - m) + ex<DT>(v[2] - m) + ex<DT>(v[3] - m);
+    for (int k0 = threadIdx.x * 4; k0 < a.K; k0 += NT * 4 * RS_U) {
+        f32x4 v[RS_U];
+#pragma unroll
+        for (int u = 0; u < RS_U; ++u) {
+            const int k = k0 + u * NT * 4;
+            v[u] = k < a.K ? *(const f32x4*)(x + k) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+        if (teacher) {
+#pragma unroll
+            for (int u = 0; u < RS_U; ++u) {
+                const int k = k0 + u * NT * 4;
+                if (k < a.K) v[u] -= *(const f32x4*)(a.center + k);
+            }
+        }
+        float lm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < RS_U; ++u) {
+            v[u] *= inv_t;
+            lm = fmaxf(lm, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
+        }
+        if (lm > m) { s *= ex<DT>(m - lm); m = lm; }       // (piece 0 of a trip is always inside the row: lm is finite)
+#pragma unroll
+        for (int u = 0; u < RS_U; ++u) s += ex<DT>(v[u][0] - m) + ex<DT>(v[u][1] - m) + ex<DT>(v[u][2] - m) + ex<DT>(v[u][3] - m);
     }
     const float wm = wave_max(m);
-    s = (m == -INFINITY) ? 0.f : s * ex<DT>(m - wm);   // idle lanes when K < 1024
+    s = (m == -INFINITY) ? 0.f : s * ex<DT>(m - wm);   // idle lanes when K < 4 NT
     s = wave_sum(s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red_m[wave] = wm; red_s[wave] = s; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+        float M = red_m[0];
+        for (int w = 1; w < NWV; ++w) M = fmaxf(M, red_m[w]);
         float S = 0.f;
-        for (int w = 0; w < 4; ++w) S += red_s[w] * ex<DT>(red_m[w] - M);
+        for (int w = 0; w < NWV; ++w) S += red_s[w] * ex<DT>(red_m[w] - M);
         a.workspace[2 * row] = M;
         a.workspace[2 * row + 1] = lg<DT>(S);
     }
 }
 
-// grid (K/256, bsplit); thread = one class k, loops over its slice of the batch
+// grid (K / 1024, bsplit); thread = FOUR consecutive classes k (16-B loads, 8-B / 16-B gradient stores -- one class per thread
+// made every access 4 or 2 bytes per lane), loops over its slice of the batch
 template <typename DT>
 __global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int b_per, float coef, float inv_pairs_b) {
     __shared__ float red[4];
@@ -61,39 +83,52 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(gv_dino_loss_args a, int
         a.teacher_temp = a.hyper[GV_HYP_TEACHER_TEMP]; a.student_temp = a.hyper[GV_HYP_STUDENT_TEMP];
     }
     if (a.loss_scale) coef *= *a.loss_scale;
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int b0 = blockIdx.y * b_per, b1 = min(a.B, b0 + b_per);
     const int V = a.V, G = a.G, B = a.B, K = a.K;
     const int ns = V * B;
     const float inv_ts = 1.0f / a.student_temp, inv_tt = 1.0f / a.teacher_temp;
-    float loss = 0.f, csum = 0.f;
+    float loss = 0.f;
     if (k < K) {
-        const float c = a.center[k];
+        f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 c = *(const f32x4*)(a.center + k);
         for (int b = b0; b < b1; ++b) {
-            float t[MAXG], tsum = 0.f;
+            f32x4 t[MAXG], tsum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int iq = 0; iq < MAXG; ++iq) {
+                t[iq] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (iq < G) {
                     const int row = ns + iq * B + b;
-                    const float raw = a.teacher[(long)(iq * B + b) * K + k];
+                    const f32x4 raw = *(const f32x4*)(a.teacher + (long)(iq * B + b) * K + k);
+                    const float rm = a.workspace[2 * row], rl = a.workspace[2 * row + 1];
                     csum += raw;
-                    t[iq] = ex<DT>((raw - c) * inv_tt - a.workspace[2 * row] - a.workspace[2 * row + 1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[iq][e] = ex<DT>((raw[e] - c[e]) * inv_tt - rm - rl);
                     tsum += t[iq];
-                } else t[iq] = 0.f;
+                }
             }
 #pragma unroll 2
             for (int v = 0; v < V; ++v) {
                 const int row = v * B + b;
-                const float s = a.student[(long)row * K + k] * inv_ts;
-                const float logp = s - a.workspace[2 * row] - a.workspace[2 * row + 1];
-                const float p = ex<DT>(logp);
-                float ts = tsum, nv = (float)G;
+                const f32x4 sv = *(const f32x4*)(a.student + (long)row * K + k);
+                const float rm = a.workspace[2 * row], rl = a.workspace[2 * row + 1];
+                f32x4 ts = tsum;
+                float nv = (float)G;
                 if (v < G) { ts -= (v == 0 ? t[0] : v == 1 ? t[1] : v == 2 ? t[2] : t[3]); nv -= 1.f; }
-                loss -= ts * logp;
-                ((DT*)a.dstudent)[(long)row * K + k] = (DT)(coef * (nv * p - ts));
+                f32x4 g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float logp = sv[e] * inv_ts - rm - rl;
+                    loss -= ts[e] * logp;
+                    g[e] = coef * (nv * ex<DT>(logp) - ts[e]);
+                }
+                DT* dst = (DT*)a.dstudent + (long)row * K + k;
+                if constexpr (sizeof(DT) == 4) *(f32x4*)dst = g;
+                else *(bf16x4*)dst = bf16x4{(bf16)g[0], (bf16)g[1], (bf16)g[2], (bf16)g[3]};
             }
         }
-        atomicAdd(a.center_sum + k, csum);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(a.center_sum + k + e, csum[e]);
     }
     loss = wave_sum(loss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loss;
@@ -113,9 +148,9 @@ template <typename DT> int dino_loss_launch(const gv_dino_loss_args* a, void* st
     if (e == hipSuccess) e = hipMemsetAsync(a->center_sum, 0, sizeof(float) * a->K, s);
     if (e != hipSuccess) GV_FAIL((int)e, "gv_dino_loss: memset failed: %s", hipGetErrorString(e));
     const int rows = (a->V + a->G) * a->B;
-    hipLaunchKernelGGL(row_stats_kernel<DT>, dim3(rows), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((row_stats_kernel<DT, 256, 2>), dim3(rows), dim3(256), 0, s, *a);
     GV_LAUNCH_CHECK("gv_dino_loss(row_stats)");
-    const int kblocks = (a->K + 255) / 256;
+    const int kblocks = (a->K + 1023) / 1024;
     int bsplit = (1024 + kblocks - 1) / kblocks;
     if (bsplit > a->B) bsplit = a->B;
     if (bsplit < 1) bsplit = 1;

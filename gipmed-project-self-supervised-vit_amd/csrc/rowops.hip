@@ -127,6 +127,55 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_kernel(gv_weightnorm_fwd_a
     }
 }
 
+// C = 256 (the DINO head's bottleneck width: 65536 rows of 1 KB): a lane holds its 16 bytes of the row, so the row is read once, and
+// a wave takes TWO rows, both requested before either is reduced (one 1-KB request in flight per wave left the pass at ~60 % of the
+// stream rate).  Same per-lane partial sums and reduction as the generic kernels: bit-identical results.
+template <typename HT>
+__global__ __launch_bounds__(256) void weightnorm_fwd256_kernel(gv_weightnorm_fwd_args a) {
+    const int lane = threadIdx.x & 63, r0 = blockIdx.x * 8 + (threadIdx.x >> 6), r1 = r0 + 4;
+    if (r0 >= a.rows) return;
+    const bool two = r1 < a.rows;
+    const f32x4 x0 = *(const f32x4*)(a.v + (long)r0 * 256 + lane * 4);
+    const f32x4 x1 = two ? *(const f32x4*)(a.v + (long)r1 * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float sc0 = a.g[r0] / sqrtf(wave_sum(x0[0]*x0[0] + x0[1]*x0[1] + x0[2]*x0[2] + x0[3]*x0[3]));
+    st4((HT*)a.w + (long)r0 * 256 + lane * 4, f32x4{x0[0]*sc0, x0[1]*sc0, x0[2]*sc0, x0[3]*sc0});
+    if (two) {
+        const float sc1 = a.g[r1] / sqrtf(wave_sum(x1[0]*x1[0] + x1[1]*x1[1] + x1[2]*x1[2] + x1[3]*x1[3]));
+        st4((HT*)a.w + (long)r1 * 256 + lane * 4, f32x4{x1[0]*sc1, x1[1]*sc1, x1[2]*sc1, x1[3]*sc1});
+    }
+}
+
+__global__ __launch_bounds__(256) void weightnorm_bwd256_kernel(gv_weightnorm_bwd_args a) {
+    const int lane = threadIdx.x & 63, r0 = blockIdx.x * 8 + (threadIdx.x >> 6);
+    if (r0 >= a.rows) return;
+    f32x4 x[2], d[2], pv[2];
+    bool has[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = r0 + 4 * k;
+        has[k] = r < a.rows;
+        const long off = (long)(has[k] ? r : r0) * 256 + lane * 4;
+        x[k] = *(const f32x4*)(a.v + off);
+        d[k] = *(const f32x4*)(a.dw + off);
+        pv[k] = a.accumulate ? *(const f32x4*)(a.dv + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!has[k]) continue;
+        const int r = r0 + 4 * k;
+        const float nn = wave_sum(x[k][0]*x[k][0] + x[k][1]*x[k][1] + x[k][2]*x[k][2] + x[k][3]*x[k][3]);
+        const float dot = wave_sum(x[k][0]*d[k][0] + x[k][1]*d[k][1] + x[k][2]*d[k][2] + x[k][3]*d[k][3]);
+        const float inv = 1.0f / sqrtf(nn);
+        const float gs = a.g[r] * inv, vd = dot * inv;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = gs * (d[k][j] - x[k][j] * inv * vd);
+        if (a.accumulate) o += pv[k];
+        *(f32x4*)(a.dv + (long)r * 256 + lane * 4) = o;
+        if (lane == 0 && a.dg) a.dg[r] = a.accumulate ? a.dg[r] + vd : vd;
+    }
+}
+
 __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(gv_weightnorm_bwd_args a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
@@ -180,8 +229,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(gv_sumsq_args a) {
     __shared__ float red[4];
     float s = 0.f;
     const long n4 = a.n >> 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 v = ((const f32x4*)a.x)[i];
+    // two pieces per trip, both requested before the first is used (one piece in flight per lane: 4.8 TB/s over the 176-MB gradient arena)
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const f32x4 v = ((const f32x4*)a.x)[i], w = ((const f32x4*)a.x)[i + stride];
+        s += v[0]*v[0] + v[1]*v[1] + v[2]*v[2] + v[3]*v[3];
+        s += w[0]*w[0] + w[1]*w[1] + w[2]*w[2] + w[3]*w[3];
+    }
+    if (i < n4) {
+        const f32x4 v = ((const f32x4*)a.x)[i];
         s += v[0]*v[0] + v[1]*v[1] + v[2]*v[2] + v[3]*v[3];
     }
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) { const float v = a.x[(n4 << 2) + threadIdx.x]; s += v * v; }
@@ -300,6 +357,11 @@ extern "C" int gv_l2norm_bwd(const gv_l2norm_bwd_args* a, void* stream) {
 }
 extern "C" int gv_weightnorm_fwd(const gv_weightnorm_fwd_args* a, void* stream) {
     GV_REQUIRE(a && a->v && a->g && a->w, GV_E_NULL, "gv_weightnorm_fwd: null pointer");
+    if (a->C == 256 && a->rows > 0) {
+        hipLaunchKernelGGL(weightnorm_fwd256_kernel<bf16>, dim3((a->rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, *a);
+        GV_LAUNCH_CHECK("gv_weightnorm_fwd");
+        return GV_OK;
+    }
     GV_ROW_LAUNCH(weightnorm_fwd_kernel<bf16>, a, "gv_weightnorm_fwd")
 }
 extern "C" int gv_l2norm_fwd_f32(const gv_l2norm_fwd_args* a, void* stream) {
@@ -312,10 +374,20 @@ extern "C" int gv_l2norm_bwd_f32(const gv_l2norm_bwd_args* a, void* stream) {
 }
 extern "C" int gv_weightnorm_fwd_f32(const gv_weightnorm_fwd_args* a, void* stream) {
     GV_REQUIRE(a && a->v && a->g && a->w, GV_E_NULL, "gv_weightnorm_fwd: null pointer");
+    if (a->C == 256 && a->rows > 0) {
+        hipLaunchKernelGGL(weightnorm_fwd256_kernel<float>, dim3((a->rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, *a);
+        GV_LAUNCH_CHECK("gv_weightnorm_fwd_f32");
+        return GV_OK;
+    }
     GV_ROW_LAUNCH(weightnorm_fwd_kernel<float>, a, "gv_weightnorm_fwd_f32")
 }
 extern "C" int gv_weightnorm_bwd(const gv_weightnorm_bwd_args* a, void* stream) {
     GV_REQUIRE(a && a->dw && a->v && a->g && a->dv, GV_E_NULL, "gv_weightnorm_bwd: null pointer");
+    if (a->C == 256 && a->rows > 0) {
+        hipLaunchKernelGGL(weightnorm_bwd256_kernel, dim3((a->rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, *a);
+        GV_LAUNCH_CHECK("gv_weightnorm_bwd");
+        return GV_OK;
+    }
     GV_ROW_LAUNCH(weightnorm_bwd_kernel, a, "gv_weightnorm_bwd")
 }
 

@@ -481,18 +481,23 @@ def test_l2norm_weightnorm(dev):
     dx = torch.empty(rows, C, dtype=bf16, device=dev)
     o.l2norm_bwd(dy, y, inv, dx, rows, C)
     close(dx, xr.grad, 2e-2, 2e-3, "l2norm bwd")
-    K = 1000
-    v = torch.randn(K, C, generator=g).to(dev); gg = (1 + 0.1 * torch.randn(K, generator=g)).to(dev)
-    w = torch.empty(K, C, dtype=bf16, device=dev)
-    o.weightnorm_fwd(v, gg, w, K, C)
-    close(w, gg[:, None] * v / v.norm(dim=1, keepdim=True), 8e-3, 1e-3, "weightnorm")
-    dw = torch.randn(K, C, generator=g).to(dev)
-    vr = v.clone().requires_grad_(True); gr = gg.clone().requires_grad_(True)
-    (gr[:, None] * vr / vr.norm(dim=1, keepdim=True)).backward(dw)
-    dv = torch.ones(K, C, device=dev); dg = torch.zeros(K, device=dev)
-    o.weightnorm_bwd(dw, v, gg, dv, dg, K, C, accumulate=True)
-    close(dv, 1 + vr.grad, 1e-4, 1e-4, "dv")
-    close(dg, gr.grad, 1e-4, 1e-4, "dg")
+    # C = 256 takes the two-rows-per-wave kernels (ragged last block at 1003 rows), any other width the generic ones
+    for K, C in ((1000, 256), (1003, 256), (37, 128)):
+        v = torch.randn(K, C, generator=g).to(dev); gg = (1 + 0.1 * torch.randn(K, generator=g)).to(dev)
+        w = torch.empty(K, C, dtype=bf16, device=dev)
+        o.weightnorm_fwd(v, gg, w, K, C)
+        close(w, gg[:, None] * v / v.norm(dim=1, keepdim=True), 8e-3, 1e-3, f"weightnorm {K}x{C}")
+        dw = torch.randn(K, C, generator=g).to(dev)
+        vr = v.clone().requires_grad_(True); gr = gg.clone().requires_grad_(True)
+        (gr[:, None] * vr / vr.norm(dim=1, keepdim=True)).backward(dw)
+        dv = torch.ones(K, C, device=dev); dg = torch.zeros(K, device=dev)
+        o.weightnorm_bwd(dw, v, gg, dv, dg, K, C, accumulate=True)
+        close(dv, 1 + vr.grad, 1e-4, 1e-4, f"dv {K}x{C}")
+        close(dg, gr.grad, 1e-4, 1e-4, f"dg {K}x{C}")
+        dv2 = torch.full((K, C), 7.0, device=dev); dg2 = torch.full((K,), 7.0, device=dev)
+        o.weightnorm_bwd(dw, v, gg, dv2, dg2, K, C, accumulate=False)
+        close(dv2, vr.grad, 1e-4, 1e-4, f"dv (overwrite) {K}x{C}")
+        close(dg2, gr.grad, 1e-4, 1e-4, f"dg (overwrite) {K}x{C}")
 
 
 # ------------------------------------------------------------------------ DINO loss
