@@ -335,6 +335,8 @@ class VitRunner:
         self.cls_last = os.environ.get("GIPVIT_CLS_ONLY_LAST", "1") != "0"
         # forward-only passes (teacher, inference) run the MLP as one launch; GIPVIT_FUSED_MLP=0 keeps fc1 / fc2 apart (A/B runs)
         self.fused_mlp = os.environ.get("GIPVIT_FUSED_MLP", "1") != "0"
+        # the CLS-only tail of the last block (n_img rows): fused Linear + LayerNorm kernels, or the tiled GEMM + a LayerNorm pass
+        self.cls_tail_fused = os.environ.get("GIPVIT_CLS_TAIL_FUSED", "0") != "0"
         self.partials = _empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device)
         self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
@@ -396,7 +398,7 @@ class VitRunner:
                 for sg in G.segs:
                     ops.attention_fwd(sg.rows(G.qkv[s]), sg.n_img, sg.N, H, self.scale, o=sg.rows(G.o[s]), lse=sg.lse[s], q_limit=ql)
             if self._cls_tail(G) and i == self.depth - 1:
-                self._last_block_tail_fwd(W, G, i, xa, fused)
+                self._last_block_tail_fwd(W, G, i, xa, fused and self.cls_tail_fused)
                 break
             if fused:
                 ops.linear_ln_fwd(G.o[s], W.w(b + "attn.proj.weight"), xb, T, D, bias=W.f(b + "attn.proj.bias"), resid=xa,
@@ -571,7 +573,7 @@ class VitRunner:
             ring_i[0] = (k + 1) % 3
             join(fin_ev[k])
             M_, g_ = (T if rows is None else rows), (G.g if g is None else g)
-            if dx_of is not None and fused_b:
+            if dx_of is not None and fused_b and (rows is None or self.cls_tail_fused):
                 nblk = ops.linear_ln_bwd(dx_of[0], dx_of[1], x, mean, rstd, gamma, g_, gb, ring[k], M_, dx_of[2], gb_scale=gb_scale)
             else:
                 if dx_of is not None:
