@@ -66,26 +66,41 @@ __global__ __launch_bounds__(PCfg::THREADS, PCfg::THREADS * WGS_PER_CU / 256) vo
     gemm_body<PCfg, TA, TB, OutT, ATOMIC, EPI>(g, (GV_LDS char*)smem_raw);
 }
 
+// Few tiles, long reduction (the DINO head's 2048-wide layers and the CLS-only tail at 128 / 640 rows: 15 - 80 workgroups, 24 - 32
+// K-steps each): with one workgroup per CU and a two-stage ring every K-step pays a whole L2 / HBM round trip, ~1 us -- 34 us for
+// K = 2048 whatever M is.  The same body on a FOUR-stage ring (128 KB of LDS, three K-steps in flight): same tiles, same
+// accumulation order, bit-identical results.
+using DCfg = Cfg<GV_GEMM_BM, GV_GEMM_BN, GV_GEMM_BK, GV_GEMM_WM, GV_GEMM_WN, 4>;
+static_assert(DCfg::LDS <= 160 * 1024, "deep ring");
 template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI>
-const char* kernel_name() {
-    static char name[96] = "";
-    if (!name[0])
-        snprintf(name, sizeof(name), "gemm_kernel<%s, %s, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false",
+__global__ __launch_bounds__(DCfg::THREADS, 1) void gemm_deep_kernel(const GemmP g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    gemm_body<DCfg, TA, TB, OutT, ATOMIC, EPI>(g, (GV_LDS char*)smem_raw);
+}
+
+template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI>
+const char* kernel_name(bool deep = false) {
+    static char name[2][96] = {"", ""};
+    if (!name[deep][0])
+        snprintf(name[deep], sizeof(name[deep]), "gemm_%skernel<%s, %s, %s, %s, %d>", deep ? "deep_" : "", TA ? "true" : "false", TB ? "true" : "false",
                  sizeof(OutT) == 4 ? "float" : "bf16", ATOMIC ? "true" : "false", EPI);
-    return name;
+    return name[deep];
 }
 
 template <bool TA, bool TB, typename OutT, bool ATOMIC, int EPI = -1>
 int launch(const GemmP& p, hipStream_t s) {
-    auto kern = gemm_kernel<TA, TB, OutT, ATOMIC, EPI>;
-    static GvLdsOptIn opt_in;        // > 64 KiB of dynamic LDS: once per kernel instantiation and device
-    if (int rc = gv_lds_opt_in(opt_in, (const void*)kern, PCfg::LDS, "gemm")) return rc;
     // persistent workgroups walk the item list; split-K launches are never persistent (their
     // atomic epilogue reuses the ring): one workgroup per (tile, k-slice)
     const int items = p.tiles_m * p.tiles_n * p.ksplit;
     // measured (tools/gemm_lab): with K = 384..2048 one workgroup per item beats a persistent walk
     const int grid = items;
     (void)PERSISTENT_GRID;
+    // at most one workgroup per CU anyway and >= 8 K-steps per workgroup: the four-stage ring
+    const bool deep = items <= gv_cu_budget() && (p.ksplit > 1 ? p.k_per_split : p.K) >= 8 * BK;
+    auto kern = deep ? gemm_deep_kernel<TA, TB, OutT, ATOMIC, EPI> : gemm_kernel<TA, TB, OutT, ATOMIC, EPI>;
+    const int lds = deep ? DCfg::LDS : PCfg::LDS;
+    static GvLdsOptIn opt_in[2];     // > 64 KiB of dynamic LDS: once per kernel instantiation and device
+    if (int rc = gv_lds_opt_in(opt_in[deep], (const void*)kern, lds, "gemm")) return rc;
     int th = -1;
     if (gvtime::enabled()) {      // algorithmic bytes: operands once, output once, epilogue operands once
         const int e = EPI >= 0 ? EPI : p.epi;
@@ -95,9 +110,9 @@ int launch(const GemmP& p, hipStream_t s) {
         if (e & GV_EPI_RESID) bytes += mn * 4;
         if (e & GV_EPI_DGELU) bytes += mn * 2;
         if (e & GV_EPI_SAVE_PRE) bytes += mn * 2;
-        th = gvtime::begin(kernel_name<TA, TB, OutT, ATOMIC, EPI>(), 2.0 * p.M * p.N * p.K, bytes, s);
+        th = gvtime::begin(kernel_name<TA, TB, OutT, ATOMIC, EPI>(deep), 2.0 * p.M * p.N * p.K, bytes, s);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), PCfg::LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PCfg::THREADS), lds, s, p);
     gvtime::end(th, s);
     GV_LAUNCH_CHECK("gv_linear");
     return GV_OK;
