@@ -136,6 +136,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// split-K with an epilogue other than ACCUM: C = epilogue(sum_s slab[s]) -- the epilogue of gemm_core.h in its order (alpha is in the
+// partial tiles already; bias, saved pre-activation, GELU, GELU' of the saved input, row factor + residual), 16 B of output columns per lane
+struct SplitEpiP {
+    const float* slab; void* C; const float* bias; const float* resid; const bf16* aux_in; bf16* aux_out; const float* row_scale;
+    long ldc, ldr, ld_aux; int M, N, S, epi;
+};
+template <typename OutT>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const SplitEpiP q) {
+    const int N4 = q.N >> 2;
+    const long MN = (long)q.M * q.N, MN4 = MN >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N4), n = (int)(i - (long)m * N4) * 4;
+        f32x4 v = *(const f32x4*)(q.slab + i * 4);
+        for (int s2 = 1; s2 < q.S; ++s2) v += *(const f32x4*)(q.slab + (long)s2 * MN + i * 4);
+        if (q.epi & GV_EPI_BIAS) v += *(const f32x4*)(q.bias + n);
+        if (q.epi & GV_EPI_SAVE_PRE) *(bf16x4*)(q.aux_out + (long)m * q.ld_aux + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        if (q.epi & GV_EPI_GELU) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]); }
+        if (q.epi & GV_EPI_DGELU) {
+            const bf16x4 a = *(const bf16x4*)(q.aux_in + (long)m * q.ld_aux + n);
+            v[0] *= dgelu_f((float)a[0]); v[1] *= dgelu_f((float)a[1]); v[2] *= dgelu_f((float)a[2]); v[3] *= dgelu_f((float)a[3]);
+        }
+        if (q.epi & GV_EPI_RESID) {
+            if (q.row_scale) v *= q.row_scale[m];
+            v += *(const f32x4*)(q.resid + (long)m * q.ldr + n);
+        }
+        if constexpr (sizeof(OutT) == 4) *(f32x4*)((float*)q.C + (long)m * q.ldc + n) = v;
+        else *(bf16x4*)((bf16*)q.C + (long)m * q.ldc + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    }
+}
+
 // one launch over up to GV_DW_GROUP_MAX weight-gradient products that reduce over the same token rows: every workgroup
 // runs ONE (problem, tile, k-slice) item of the split-K dW kernel, partial tiles go to the shared slab, one reduce
 // launch folds all problems.  Items are slice-major over the concatenated tile lists, XCD-contiguous like make_walk.
@@ -392,6 +422,22 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
             }
         }
     }
+    // Few tiles, a long reduction and an epilogue other than ACCUM (the DINO head's 2048-wide layers, the CLS-only tail's fc2 at 128 /
+    // 640 rows: 15 - 80 workgroups with 24 - 32 serial K-steps of ~1 us): with a caller's scratch, split K over the idle CUs as well --
+    // >= 4 K-steps per slice, at most one workgroup per CU -- and let ONE pass sum the partial tiles and apply the epilogue.
+    bool epi_split = false;
+    if (p.ksplit == 1 && !ta && !(e & (GV_EPI_ACCUM | GV_EPI_POS)) && (a->N & 7) == 0 && a->workspace && gv_aligned(a->workspace, 16) && !a->colsum_a &&
+        (!(e & (GV_EPI_DGELU | GV_EPI_SAVE_PRE)) || a->ld_aux % 4 == 0)) {
+        const int tiles = p.tiles_m * p.tiles_n, ksteps = (a->K + BK - 1) / BK;
+        if (tiles <= 96 && ksteps >= 16) {
+            int S = gv_cu_budget() / tiles < ksteps / 4 ? gv_cu_budget() / tiles : ksteps / 4;
+            if (S >= 2) {
+                const int per = (ksteps + S - 1) / S;
+                S = (ksteps + per - 1) / per;
+                if ((long)S * a->M * a->N * 4 <= a->workspace_bytes) { p.k_per_split = per * BK; p.ksplit = S; epi_split = true; }
+            }
+        }
+    }
     // plan mode (gv_workspace_bytes) applies the launch's own fit test below: a slab that does not fit the scratch is not used (atomics)
     if (g_plan) { const long need = p.ksplit > 1 ? (long)p.ksplit * a->M * a->N * 4 : 0; g_plan_bytes = need <= a->workspace_bytes ? need : 0; return GV_OK; }
     bool slab = false;
@@ -401,6 +447,16 @@ extern "C" int gv_linear(const gv_linear_args* a, void* stream) {
     }
     auto finish = [&](int rc) -> int {
         if (rc != GV_OK || !slab) return rc;
+        if (epi_split) {
+            SplitEpiP q{(const float*)p.slab, a->C, a->bias, a->resid, (const bf16*)a->aux_in, (bf16*)a->aux_out, a->row_scale,
+                        a->ldc, a->ldr, a->ld_aux, a->M, a->N, p.ksplit, e};
+            const long MN4e = (long)a->M * a->N / 4;
+            long blk = (MN4e + 255) / 256; if (blk > 2048) blk = 2048;
+            if (a->c_is_f32) hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3((unsigned)blk), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL(splitk_epilogue_kernel<bf16>, dim3((unsigned)blk), dim3(256), 0, s, q);
+            GV_LAUNCH_CHECK("gv_linear(splitk_epilogue)");
+            return GV_OK;
+        }
         const long MN4 = (long)a->M * a->N / 4;
         long blocks = (MN4 + 255) / 256; if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.slab, (float*)a->C, MN4, p.ksplit,

@@ -341,7 +341,8 @@ class VitRunner:
         self.partials_ring = [self.partials] + [_empty((L.LN_PARTIAL_BLOCKS, 3, self.D), f32, device) for _ in range(2)]
         self.cs_ws = _empty((64 * 4 * self.D,), f32, device)
         self.one = torch.ones(1, dtype=f32, device=device)
-        self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
+        self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs of the stream the weight gradients run on (the side stream when there is one)
+        self.ws_main = _empty((16 << 20) // 4, f32, device)                              # ... of the few-row products of the CLS-only tail queued on the other one
         cuda = torch.device(device).type == "cuda"
         self.side = None
         if cuda and os.environ.get("GIPVIT_DW_STREAM", "1") != "0":
@@ -474,8 +475,10 @@ class VitRunner:
         if fused:
             ops.linear_ln_fwd(G.c_h, W.w(b + "mlp.fc2.weight"), G.c_xc, n, 4 * D, bias=W.f(b + "mlp.fc2.bias"), resid=G.c_xb, row_scale=rs_m)
         else:
+            # (a few hundred rows, a 4 D-deep reduction: gv_linear splits K when handed a scratch -- the one of the stream this pass is queued on)
+            on_side = self.side is not None and xa.is_cuda and torch.cuda.current_stream() == self.side
             ops.linear(G.c_h, W.w(b + "mlp.fc2.weight"), G.c_xc, n, D, 4 * D, epilogue=E.EPI_BIAS | E.EPI_RESID,
-                       bias=W.f(b + "mlp.fc2.bias"), resid=G.c_xb, row_scale=rs_m)
+                       bias=W.f(b + "mlp.fc2.bias"), resid=G.c_xb, row_scale=rs_m, workspace=self.ws if on_side else self.ws_main)
 
     def prepare_backward(self, G: VitGroup):
         """Zero the backward scratch that is accumulated into or only partly written: the residual gradient (the final norm's backward
@@ -577,7 +580,7 @@ class VitRunner:
                 nblk = ops.linear_ln_bwd(dx_of[0], dx_of[1], x, mean, rstd, gamma, g_, gb, ring[k], M_, dx_of[2], gb_scale=gb_scale)
             else:
                 if dx_of is not None:
-                    ops.linear(dx_of[0], dx_of[1], dy, M_, D, dx_of[2], trans_b=True)
+                    ops.linear(dx_of[0], dx_of[1], dy, M_, D, dx_of[2], trans_b=True, workspace=self.ws_main if rows is not None else None)
                 ops.layernorm_bwd(dy, x, mean, rstd, gamma, g_, gb, ring[k], M_, D, gb_scale=gb_scale)
                 nblk = L.LN_PARTIAL_BLOCKS
             if side is None:
@@ -762,13 +765,19 @@ class HeadRunner:
         self.ws = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, device)   # split-K slabs
         self.ws_side = None                                                           # second one, for products queued on a side stream
 
-    def forward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers):
+    def forward(self, W: Weights, wn: torch.Tensor, hb: HeadBuffers, on_side: bool = False):
+        """``on_side``: the call is queued on the engine's side stream (the teacher's head beside the student's forward): its
+        split-K products then take the side stream's scratch.  (A few hundred rows against 2048-deep reductions: gv_linear
+        splits K when it is handed a scratch buffer.)"""
         R, D, Hd, Bt, K, E = hb.R, self.D, self.hidden, self.bott, self.K, L
+        if on_side and self.ws_side is None:
+            self.ws_side = _empty((L.lib.gv_linear_workspace_bytes() // 4,), f32, hb.feats.device)
+        ws = self.ws_side if on_side else self.ws
         ops.linear(hb.feats, W.w("mlp.0.weight"), hb.h1, R, Hd, D, epilogue=E.EPI_BIAS | E.EPI_GELU | E.EPI_SAVE_PRE,
                    bias=W.f("mlp.0.bias"), aux_out=hb.h1p)
         ops.linear(hb.h1, W.w("mlp.2.weight"), hb.h2, R, Hd, Hd, epilogue=E.EPI_BIAS | E.EPI_GELU | E.EPI_SAVE_PRE,
-                   bias=W.f("mlp.2.bias"), aux_out=hb.h2p)
-        ops.linear(hb.h2, W.w("mlp.4.weight"), hb.z, R, Bt, Hd, epilogue=E.EPI_BIAS, bias=W.f("mlp.4.bias"))
+                   bias=W.f("mlp.2.bias"), aux_out=hb.h2p, workspace=ws)
+        ops.linear(hb.h2, W.w("mlp.4.weight"), hb.z, R, Bt, Hd, epilogue=E.EPI_BIAS, bias=W.f("mlp.4.bias"), workspace=ws)
         ops.l2norm_fwd(hb.z, hb.zn, hb.inv, R, Bt)
         ops.linear(hb.zn, wn, hb.logits, R, K, Bt)
 
@@ -802,10 +811,10 @@ class HeadRunner:
         ops.linear(hb.dz, W.w("mlp.4.weight"), hb.dh2, R, Hd, Bt, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h2p)
         on_side(lambda ws: ops.linear(hb.dh2, hb.h1, W.g("mlp.2.weight"), Hd, Hd, R, trans_a=True, trans_b=True, epilogue=ACC,
                                       colsum_a=W.g("mlp.2.bias"), workspace=ws))
-        ops.linear(hb.dh2, W.w("mlp.2.weight"), hb.dh1, R, Hd, Hd, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h1p)
+        ops.linear(hb.dh2, W.w("mlp.2.weight"), hb.dh1, R, Hd, Hd, trans_b=True, epilogue=E.EPI_DGELU, aux_in=hb.h1p, workspace=self.ws)
         on_side(lambda ws: ops.linear(hb.dh1, hb.feats, W.g("mlp.0.weight"), Hd, D, R, trans_a=True, trans_b=True, epilogue=ACC,
                                       colsum_a=W.g("mlp.0.bias"), workspace=ws))
-        ops.linear(hb.dh1, W.w("mlp.0.weight"), hb.dfeats, R, D, Hd, trans_b=True)
+        ops.linear(hb.dh1, W.w("mlp.0.weight"), hb.dfeats, R, D, Hd, trans_b=True, workspace=self.ws)
 
 
 # --------------------------------------------------------------------------- #
@@ -1025,7 +1034,7 @@ class DinoEngine:
         if t_side is not None:
             with torch.cuda.stream(side):
                 self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats, fill=fill)
-                self.head.forward(self.tH, self.wn_t, self.hb_t)
+                self.head.forward(self.tH, self.wn_t, self.hb_t, on_side=True)
                 self._ev_join.record(side)
         else:
             self.vit.forward(self.tW, self.g_teach, t_src, t_win, self.mean, self.std, self.hb_t.feats, fill=fill)

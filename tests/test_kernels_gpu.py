@@ -109,6 +109,46 @@ def test_linear_epilogues(dev):
     close(Cf, 0.25 * (A.float() @ B.float().t()), 1e-4, 1e-4, "alpha")
 
 
+@pytest.mark.parametrize("M,N,K", [(640, 2048, 2048), (128, 256, 2048), (640, 384, 1536), (100, 384, 1024), (640, 1536, 384)])
+def test_linear_few_rows_split_k_epilogue(dev, M, N, K):
+    """Few tiles and a long reduction: handed a scratch buffer, gv_linear splits K over the idle CUs and one pass sums the partial
+    tiles and applies the epilogue (the DINO head's 2048-wide layers, the CLS-only tail).  Exact on integer data against the
+    unsplit call (no scratch), every epilogue of the path against fp32 torch, NN and NT forms, one guard row behind the outputs.
+    (640 x 1536 x 384: too short a reduction to split -- the scratch must change nothing.)"""
+    o, l = ops(), L()
+    ws = torch.empty(32 << 20, dtype=f32, device=dev)
+    A, B = ints((M, K), dev, seed=41), ints((N, K), dev, seed=42)
+    bias_i = torch.arange(N, dtype=f32, device=dev) % 5 - 2
+    ref = A.float() @ B.float().t()
+    for tb, Bop in ((False, B), (True, B.t().contiguous())):
+        C0 = torch.full((M + 1, N), 9.0, dtype=f32, device=dev); C1 = C0.clone()
+        o.linear(A, Bop, C0, M, N, K, trans_b=tb, epilogue=l.EPI_BIAS, bias=bias_i)
+        o.linear(A, Bop, C1, M, N, K, trans_b=tb, epilogue=l.EPI_BIAS, bias=bias_i, workspace=ws)
+        assert torch.equal(C0, C1) and torch.equal(C1[:M], ref + bias_i) and float(C1[M].min()) == 9.0, f"integer data, trans_b={tb}"
+    g = torch.Generator().manual_seed(43)
+    Af = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(bf16)
+    Bf = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(bf16)
+    bias = torch.randn(N, generator=g).to(dev); resid = torch.randn(M, N, generator=g).to(dev)
+    rs = (torch.rand(M, generator=g) + 0.5).to(dev)
+    reff = Af.float() @ Bf.float().t()
+    C = torch.full((M + 1, N), 9.0, dtype=bf16, device=dev); pre = torch.full((M + 1, N), 9.0, dtype=bf16, device=dev)
+    o.linear(Af, Bf, C, M, N, K, epilogue=l.EPI_BIAS | l.EPI_GELU | l.EPI_SAVE_PRE, bias=bias, aux_out=pre, workspace=ws)
+    close(pre[:M], reff + bias, 1e-2, 1e-2, "pre")
+    close(C[:M], torch.nn.functional.gelu(reff + bias), 1e-2, 1e-2, "gelu")
+    assert float(C[M].float().min()) == 9.0 and float(pre[M].float().min()) == 9.0
+    Cf = torch.full((M + 1, N), 9.0, dtype=f32, device=dev)
+    o.linear(Af, Bf, Cf, M, N, K, epilogue=l.EPI_BIAS | l.EPI_RESID, bias=bias, resid=resid, row_scale=rs, workspace=ws)
+    close(Cf[:M], (reff + bias) * rs[:, None] + resid, 2e-4, 2e-4, "bias + row factor + residual")
+    assert float(Cf[M].min()) == 9.0
+    aux = torch.randn(M, N, generator=g).to(dev).to(bf16)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    o.linear(Af, Bf.t().contiguous(), C, M, N, K, trans_b=True, epilogue=l.EPI_DGELU, aux_in=aux, workspace=ws)
+    close(C[:M], reff * x.grad, 1e-2, 1e-2, "dgelu")
+    o.linear(Af, Bf, Cf, M, N, K, alpha=0.25, workspace=ws)
+    close(Cf[:M], 0.25 * reff, 1e-4, 1e-4, "alpha")
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 384, 128), (2500, 1152, 384), (4099, 1536, 384), (3000, 384, 1536), (47000, 768, 128), (33000, 384, 256),
                                    (44160, 1536, 384), (44160, 1152, 384), (25216, 1536, 384), (9999, 3072, 768), (100000, 1152, 128)])
 def test_linear_wide_panel(dev, M, N, K):
