@@ -17,6 +17,13 @@
 #include "gv_common.h"
 #include <type_traits>
 
+#ifdef GV_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[64 * 16];
+#define AST(i) do { if (blockIdx.x < 64 && threadIdx.x == 0) g_attn_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int gv_lab_attn_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)); }
+#else
+#define AST(i)
+#endif
 namespace {
 
 __device__ __attribute__((aligned(256))) unsigned short attn_zero_page[128];
@@ -106,6 +113,9 @@ __device__ __forceinline__ void attn_fwd_body(const gv_attention_fwd_args a, con
     GV_LDS char* Vimg = smem + (lp * 2 + 1) * IMG;
     const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
     const float c = a.scale * 1.4426950408889634f;
+    // q_limit: only the first query rows are wanted -- whole 32-row groups, so that the backward with the same limit finds o / lse
+    // valid for every row its first half-step touches
+    const int QE = (a.q_limit > 0 && ((a.q_limit + 31) & ~31) < N) ? ((a.q_limit + 31) & ~31) : N;
 
     // this wave's Q fragments for all its query blocks: issued BEFORE the staging wait so the
     // global-load latencies of Q, K and V overlap
@@ -129,7 +139,7 @@ __device__ __forceinline__ void attn_fwd_body(const gv_attention_fwd_args a, con
     auto round = [&](auto RDc) {
         constexpr int rd = decltype(RDc)::value;
         const int qb = wq + rd * WPP;
-        if (qb >= NQB || qb * QB >= N) return;
+        if (qb >= NQB || qb * QB >= QE) return;
         f32x4 s[NKT][QT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -282,6 +292,7 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
     const int N = a.N, H = a.H;
     const long ld = 3L * H * 64, ldo = (long)H * 64;
     const bf16* qkv = (const bf16*)a.qkv;
+    AST(0);
 
     // ---- stage Q, K, dO of every pair; delta and lse into LDS
     for (int pr = 0; pr < PAIRS; ++pr) {
@@ -349,6 +360,7 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    AST(1);
     if (dq_has) {
         GV_LDS char* P0 = smem + dq_pr * PER_PAIR;
         GV_LDS float* dl = (GV_LDS float*)(P0 + 3 * IMG + NDS * DST);
@@ -367,6 +379,7 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
         dl[NP + dq_q] = lse_q;
     }
     __syncthreads();
+    AST(2);
 
     // this wave's K fragments (B operands: lane = key, 8 consecutive d)
 #pragma unroll
@@ -383,7 +396,10 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
 
     // 64 queries per barrier pair: phase A runs twice (two 32-query halves, registers as for one) and
     // fills both halves of the dS^T image, phase B then has 16 dQ tiles to spread over the waves
-    const int nqc2 = (N + 32 * QH - 1) / (32 * QH);
+    // q_limit: d_o is zero behind the first q_limit query rows -> whole 32-query halves behind them contribute nothing to dK / dV
+    // and have dQ = 0: they are skipped (their dQ rows are zero-filled at the end)
+    const int QE = (a.q_limit > 0 && ((a.q_limit + 31) & ~31) < N) ? ((a.q_limit + 31) & ~31) : N;
+    const int nqc2 = (QE + 32 * QH - 1) / (32 * QH);
     for (int qc2 = 0; qc2 < nqc2; ++qc2) {
         // NDS = 2: step i writes image i & 1.  Its readers (phase B of step i) come before phase A of step i + 1 in every wave's
         // program order, hence before the barrier of step i + 1 -- and image i & 1 is next written in step i + 2, behind that barrier
@@ -391,7 +407,7 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
 #pragma unroll
         for (int half = 0; half < QH; ++half) {
             const int qc = qc2 * QH + half;
-            if (qc * 32 >= N) break;
+            if (qc * 32 >= QE) break;
             // ---- phase A: S, dP for [32 q] x [this wave's keys]
             f32x4 s[2][KT], dp[2][KT];
 #pragma unroll
@@ -458,11 +474,13 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
                         bf16x4{(bf16)ds[qt][kt][0], (bf16)ds[qt][kt][1], (bf16)ds[qt][kt][2], (bf16)ds[qt][kt][3]};
             }
         }
+        AST(3 + 3 * qc2);
         __syncthreads();
+        AST(4 + 3 * qc2);
         // ---- phase B: dQ^T[d][q] = sum_key K[key][d] dS[q][key]; 16 (qt, dt) tiles over the pair's waves
         for (int tile = kb; tile < 8 * QH; tile += NKB) {
             const int qt = tile >> 2, dt = tile & 3;
-            if (qc2 * 32 * QH + qt * 16 >= N) continue;
+            if (qc2 * 32 * QH + qt * 16 >= QE) continue;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NK32; ++ks) {
@@ -479,7 +497,12 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
                 *(bf16x4*)((bf16*)a.dqkv + ((long)img * N + q) * ld + h * 64 + dt * 16 + 4 * g) =
                     bf16x4{(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
         }
+        AST(5 + 3 * qc2);
         if constexpr (NDS == 1) __syncthreads();
+    }
+    if (valid) {        // skipped queries: dQ = 0 (4 rows x 128 B per wave-instruction)
+        for (int q = QE + kb * 4 + g; q < N; q += NKB * 4)
+            *(bf16x4*)((bf16*)a.dqkv + ((long)img * N + q) * ld + h * 64 + li * 4) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
     }
     // ---- dK, dV: lane = key, rows d = 16 dt + 4 g + r
     if (valid) {
@@ -496,6 +519,8 @@ __global__ __launch_bounds__((BwdCfg<NKT, KT>::NW * 64), ((NKT >= 14 || BwdCfg<N
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AST(15);
 }
 
 template <int NKT> int launch_fwd(const gv_attention_fwd_args* a, hipStream_t s) {
@@ -546,6 +571,7 @@ extern "C" int gv_attention_fwd_varlen(const gv_attention_fwd_varlen_args* v, vo
         seg[i].qkv = (const char*)v->qkv + row * 3 * v->H * 64 * 2;
         seg[i].o = (char*)v->o + row * v->H * 64 * 2;
         seg[i].lse = v->lse[i]; seg[i].n_img = v->n_img[i]; seg[i].N = v->N[i]; seg[i].H = v->H; seg[i].scale = v->scale;
+        seg[i].q_limit = v->q_limit;
         row += (long)v->n_img[i] * v->N[i];
     }
     // one launch for a long + a short segment (either order); any other mix runs one launch per segment
@@ -573,6 +599,25 @@ extern "C" int gv_attention_fwd(const gv_attention_fwd_args* a, void* stream) {
     GV_REQUIRE(a->n_img > 0 && a->H > 0 && a->N > 0 && a->N <= 288, GV_E_SHAPE, "gv_attention_fwd: need 0 < N <= 288 (got %d)", a->N);
     GV_REQUIRE(gv_aligned(a->qkv, 16) && gv_aligned(a->o, 16), GV_E_ALIGN, "gv_attention_fwd: qkv/o must be 16-byte aligned");
     return launch_fwd_any(a, (hipStream_t)stream);
+}
+
+extern "C" int gv_attention_bwd_varlen(const gv_attention_bwd_varlen_args* v, void* stream) {
+    GV_REQUIRE(v && v->qkv && v->o && v->d_o && v->dqkv, GV_E_NULL, "gv_attention_bwd_varlen: null pointer");
+    GV_REQUIRE(v->n_seg >= 1 && v->n_seg <= GV_ATTN_MAX_SEG && v->H > 0, GV_E_SHAPE, "gv_attention_bwd_varlen: 1..%d segments, H > 0", GV_ATTN_MAX_SEG);
+    long row = 0;
+    for (int i = 0; i < v->n_seg; ++i) {
+        GV_REQUIRE(v->n_img[i] > 0 && v->N[i] > 0 && v->N[i] <= 288 && v->lse[i], GV_E_SHAPE, "gv_attention_bwd_varlen: segment %d: need n_img > 0, 0 < N <= 288, lse", i);
+        gv_attention_bwd_args seg;
+        seg.qkv = (const char*)v->qkv + row * 3 * v->H * 64 * 2;
+        seg.o = (const char*)v->o + row * v->H * 64 * 2;
+        seg.d_o = (const char*)v->d_o + row * v->H * 64 * 2;
+        seg.dqkv = (char*)v->dqkv + row * 3 * v->H * 64 * 2;
+        seg.lse = v->lse[i]; seg.n_img = v->n_img[i]; seg.N = v->N[i]; seg.H = v->H; seg.scale = v->scale;
+        seg.q_limit = v->q_limit;
+        if (int rc = gv_attention_bwd(&seg, stream)) return rc;
+        row += (long)v->n_img[i] * v->N[i];
+    }
+    return GV_OK;
 }
 
 extern "C" int gv_attention_bwd(const gv_attention_bwd_args* a, void* stream) {
